@@ -1,0 +1,160 @@
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE's own
+`model.py` / `model_convlstm.py` (imported unmodified from /root/reference) on
+CPU.  Container-only test tooling: /root/reference does not exist on the GPU
+box, only the committed .npz fixtures travel.
+
+`model.py` imports `model_feature`, which needs torchvision (absent) and a
+network fetch of ImageNet weights (`mobilenet_v2(pretrained=True)`,
+model_feature.py:59).  As SURVEY.md 8(c) prescribes, a stand-in module named
+`model_feature` is placed in `sys.modules` whose `ReMobileNetV2` is the
+structural restatement of torchvision's MobileNetV2 `.features` (same key
+names, 2 223 872 parameters); everything else -- UAVSal, SRF-Net, dwBlock,
+STBlock, teConv_sub, ConvTWA(Cell), ConvLSTMCell -- executes from the
+reference's source.  Weights and inputs come from
+`iip_uavsal_saliency_amd.synth`, so only outputs are stored.
+
+Usage:  PYTHONDONTWRITEBYTECODE=1 python oracle/make_goldens.py
+"""
+import hashlib
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+from iip_uavsal_saliency_amd import synth      # noqa: E402
+from oracle.uavsal_ref import _Backbone         # noqa: E402  (torchvision stand-in only)
+
+
+def import_reference():
+    class ReMobileNetV2(nn.Module):
+        def __init__(self, name="mobilenet_v2"):
+            super().__init__()
+            self.features = _Backbone().features
+
+        def forward(self, x):
+            x1 = self.features[0:2](x)
+            x2 = self.features[2:4](x1)
+            x3 = self.features[4:7](x2)
+            x4 = self.features[7:14](x3)
+            x5 = self.features[14:18](x4)
+            return x1, x2, x3, x4, x5
+
+    mf = types.ModuleType("model_feature")
+    mf.ReMobileNetV2 = ReMobileNetV2
+    mf.ReVGG = ReMobileNetV2
+    mf.ReResNet = ReMobileNetV2
+    sys.modules["model_feature"] = mf
+    sys.path.insert(0, REF)
+    import model as ref_model                 # /root/reference/model.py
+    import model_convlstm as ref_rnn          # /root/reference/model_convlstm.py
+    return ref_model, ref_rnn
+
+
+def sub(t, stride):
+    a = t.detach().contiguous().view(-1).numpy()
+    return a[::stride].astype(np.float32).copy()
+
+
+def inputs(n, H, W, seed=0, t0=0):
+    h, w = H // 8, W // 8
+    x = torch.from_numpy(synth.normalize_frames(synth.synth_frames_u8(n, H, W, seed, t0)))
+    cb = [torch.from_numpy(synth.gauss_priors(n, h, w)), torch.from_numpy(synth.ob_priors(n, h, w, seed=seed))]
+    return x, cb, torch.zeros(1, 256, h, w)
+
+
+def weights_digest(model):
+    hsh = hashlib.sha256()
+    for k, v in model.state_dict().items():
+        hsh.update(k.encode())
+        hsh.update(v.detach().contiguous().numpy().tobytes())
+    return hsh.hexdigest()
+
+
+def run_case(ref_model, name, H, W, T, B=1, seed=0, tap_stride=13, state_stride=3, calls=1):
+    n = B * T
+    model = ref_model.UAVSal(cnn_type="mobilenet_v2", time_dims=T, num_stblock=2, bias_type=[1, 1, 1],
+                             iosize=[H, W, H // 8, W // 8], planes=256, pre_model_path="")
+    synth.load_synth_weights(model, seed)
+    model.eval()
+    taps = {}
+
+    def grab(key):
+        def hook(mod, inp, out):
+            taps[key] = out[0] if isinstance(out, tuple) else out
+        return hook
+
+    model.sfnet.register_forward_hook(grab("sfnet"))
+    model.st_layer[0].register_forward_hook(grab("st0"))
+    model.st_layer[1].register_forward_hook(grab("st1"))
+    model.fucb_layer.register_forward_hook(grab("fust_in_cb"))
+    model.fucbst_layer.register_forward_hook(grab("prefuse"))
+    model.rnn.register_forward_hook(grab("rnn"))
+    model.conv_out_st.register_forward_hook(grab("logits"))
+
+    rec = {"H": H, "W": W, "T": T, "B": B, "seed": seed, "calls": calls,
+           "tap_stride": tap_stride, "state_stride": state_stride,
+           "weights_sha256": np.frombuffer(bytes.fromhex(weights_digest(model)), dtype=np.uint8)}
+    state = None
+    with torch.no_grad():
+        for c in range(calls):
+            x, cb, zero = inputs(n, H, W, seed, t0=c * n)
+            out, st = model(x, cb, [zero] if state is None else state)
+            state = [st[0].detach()]
+            sfx = "" if c == 0 else f"_call{c}"
+            rec["out" + sfx] = out.numpy().astype(np.float32)
+            rec["logits" + sfx] = taps["logits"].numpy().astype(np.float32)
+            rec["state" + sfx] = sub(st[0], state_stride)
+            rec["state_sum" + sfx] = np.float64(st[0].double().sum().item())
+            if c == 0:
+                for k in ("sfnet", "st0", "st1", "fust_in_cb", "prefuse", "rnn"):
+                    t = taps[k]
+                    rec["tap_" + k] = sub(t, tap_stride)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **rec)
+    print("%-28s out %.5f..%.5f  logits std %.3f  -> %s (%.0f KB)" % (
+        name, rec["out"].min(), rec["out"].max(), rec["logits"].std(), os.path.basename(path),
+        os.path.getsize(path) / 1024))
+
+
+def run_convlstm(ref_rnn, seed=0):
+    """One ConvLSTMCell step from the reference's model_convlstm.py (imports as-is)."""
+    hid, h, w = 32, 9, 11
+    cell = ref_rnn.ConvLSTMCell((h, w), hid, hid, (3, 3), bias=False)
+    wgt = synth.synth_tensor("convlstm.rnn_conv.weight", (4 * hid, 2 * hid, 3, 3), seed)
+    cell.rnn_conv.weight.data.copy_(torch.from_numpy(wgt))
+    mk = lambda nm: torch.from_numpy((synth.hash_normal(nm, hid * h * w, seed)).astype(np.float32)).view(1, hid, h, w)
+    x, hp, cp = mk("convlstm.x"), mk("convlstm.h"), mk("convlstm.c")
+    with torch.no_grad():
+        hn, cn = cell(x, (hp, cp))
+    np.savez_compressed(os.path.join(OUT, "convlstm_step.npz"), hid=hid, hw=np.array([h, w]), seed=seed,
+                        h_next=hn.numpy(), c_next=cn.numpy())   # x/h/c/weight regenerate from synth
+    print("convlstm_step               h_next std %.4f" % hn.std().item())
+
+
+def main():
+    if not os.path.isdir(REF):
+        raise SystemExit("reference not present: goldens can only be generated in the authoring container")
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    ref_model, ref_rnn = import_reference()
+    run_case(ref_model, "e2e_96x160_T4", 96, 160, 4)
+    run_case(ref_model, "e2e_96x160_B4T5", 96, 160, 5, B=4, tap_stride=61)             # Demo_Test.py default chunking
+    run_case(ref_model, "e2e_96x160_T4_two_calls", 96, 160, 4, calls=2)  # carried state
+    run_case(ref_model, "e2e_72x104_T3", 72, 104, 3)                     # odd sizes: 9x13 -> 5x7 -> 3x4
+    run_case(ref_model, "e2e_288x512_T8", 288, 512, 8, tap_stride=211, state_stride=29)
+    run_case(ref_model, "e2e_360x640_T8", 360, 640, 8, tap_stride=331, state_stride=47)
+    run_convlstm(ref_rnn)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,104 @@
+"""The oracle (CPU restatement, oracle/uavsal_ref.py) against the golden vectors that
+oracle/make_goldens.py produced by running the reference's own model.py on CPU."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from iip_uavsal_saliency_amd import synth
+from oracle import uavsal_ref as R
+
+CASES = ["e2e_96x160_T4", "e2e_96x160_B4T5", "e2e_96x160_T4_two_calls", "e2e_72x104_T3"]
+BIG = ["e2e_288x512_T8"]
+
+
+def make_inputs(n, H, W, seed=0, t0=0):
+    h, w = H // 8, W // 8
+    x = torch.from_numpy(synth.normalize_frames(synth.synth_frames_u8(n, H, W, seed, t0)))
+    cb = [torch.from_numpy(synth.gauss_priors(n, h, w)), torch.from_numpy(synth.ob_priors(n, h, w, seed=seed))]
+    return x, cb
+
+
+def _sub(t, stride):
+    return t.contiguous().view(-1).numpy()[::stride]
+
+
+@pytest.mark.parametrize("name", CASES + BIG)
+def test_oracle_matches_reference_golden(name, golden_dir):
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    H, W, T, B = int(g["H"]), int(g["W"]), int(g["T"]), int(g["B"])
+    model = R.build_oracle(time_dims=T, seed=int(g["seed"]))
+    n = B * T
+    state = None
+    for c in range(int(g["calls"])):
+        x, cb = make_inputs(n, H, W, int(g["seed"]), t0=c * n)
+        taps = {}
+        out, st = model(x, cb, state, taps)
+        state = [st[0]]
+        sfx = "" if c == 0 else f"_call{c}"
+        # same ATen CPU operators as the reference -> agreement to fp32 round-off
+        np.testing.assert_allclose(out.numpy(), g["out" + sfx], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(taps["logits"].numpy(), g["logits" + sfx], rtol=0, atol=5e-5)
+        np.testing.assert_allclose(_sub(st[0], int(g["state_stride"])), g["state" + sfx], rtol=0, atol=2e-5)
+        if c == 0:
+            for k in ("sfnet", "st0", "st1", "fust_in_cb", "prefuse", "rnn"):
+                np.testing.assert_allclose(_sub(taps[k], int(g["tap_stride"])), g["tap_" + k], rtol=0, atol=5e-5)
+
+
+def test_state_dict_schema_known_answer():
+    """Reference known answer: 51.59 MB params+buffers (Tools/Getmodelsize_demo.py:93);
+    SURVEY.md 8(b): 685 entries, 13 407 338 parameters."""
+    m = R.RefUAVSal()
+    sd = m.state_dict()
+    assert len(sd) == 685
+    assert sum(p.numel() for p in m.parameters()) == 13407338
+    mb = (sum(p.numel() * p.element_size() for p in m.parameters())
+          + sum(b.numel() * b.element_size() for b in m.buffers())) / 1024 / 1024
+    assert "%.2f" % mb == "51.59"
+    assert sd["rnn.cell_list.0.rnn_conv.weight"].shape == (256, 512, 3, 3)
+    assert sd["sfnet.features.features.18.0.weight"].shape == (1280, 320, 1, 1)
+
+
+def test_context_tiling_quirk():
+    """model.py:361: frame k gets the context of chunk k mod B (not k // T)."""
+    g_dir = os.path.join(os.path.dirname(__file__), "golden")
+    model = R.build_oracle(time_dims=4)
+    x, cb = make_inputs(8, 96, 160)
+    taps = {}
+    model(x, cb, None, taps)
+    ctx_in = taps["fust_in_cb"]          # depends on ctx through fucb_layer
+    assert ctx_in.shape[0] == 8
+
+
+def test_temporal_difference_edges():
+    x1 = torch.arange(5, dtype=torch.float32).view(5, 1, 1, 1) ** 2
+    d = R.temporal_differences(x1).view(5, 2)
+    # frame 0: [x1-x0, x0-x1]; middle: [xi-x(i-1), xi-x(i+1)]; last: [xl-x(l-1), x(l-1)-xl]
+    assert d[0].tolist() == [1.0, -1.0]
+    assert d[2].tolist() == [3.0, -5.0]
+    assert d[4].tolist() == [7.0, -7.0]
+    with pytest.raises(RuntimeError):
+        R.temporal_differences(x1[:1])
+
+
+def test_convlstm_step_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "convlstm_step.npz"))
+    hid, (h, w), seed = int(g["hid"]), g["hw"], int(g["seed"])
+    wgt = torch.from_numpy(synth.synth_tensor("convlstm.rnn_conv.weight", (4 * hid, 2 * hid, 3, 3), seed))
+    mk = lambda nm: torch.from_numpy(synth.hash_normal(nm, hid * h * w, seed).astype(np.float32)).view(1, hid, h, w)
+    hn, cn = R.convlstm_cell_step(wgt, mk("convlstm.x"), mk("convlstm.h"), mk("convlstm.c"))
+    np.testing.assert_allclose(hn.numpy(), g["h_next"], atol=1e-6)
+    np.testing.assert_allclose(cn.numpy(), g["c_next"], atol=1e-6)
+
+
+def test_forward_clips_equals_independent_calls():
+    model = R.build_oracle(time_dims=3)
+    x, cb = make_inputs(6, 72, 104)
+    xc = x.view(2, 3, 3, 72, 104)
+    cbc = [cb[0].view(2, 3, 8, 9, 13), cb[1].view(2, 3, 20, 9, 13)]
+    out, st = model.forward_clips(xc, cbc)
+    o0, s0 = model(x[:3], [cb[0][:3], cb[1][:3]], None)
+    o1, s1 = model(x[3:], [cb[0][3:], cb[1][3:]], None)
+    assert torch.equal(out[0], o0) and torch.equal(out[1], o1)
+    assert torch.equal(st[0:1], s0[0]) and torch.equal(st[1:2], s1[0])
