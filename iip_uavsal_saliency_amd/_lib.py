@@ -1,0 +1,134 @@
+"""ctypes binding of libuavsal_hip.so (C ABI: include/uavsal_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing or a
+launch fails, a RuntimeError is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "libuavsal_hip.so")
+
+PREC = {"f32": 0, "bf16x3": 1, "bf16": 2}
+ACT_NONE, ACT_RELU6, ACT_SIGMOID = 0, 1, 2
+EPI_AFFINE, EPI_TWA = 0, 1
+
+_ERR = {-1: "UAVSAL_EINVAL (null pointer / non-positive size)",
+        -2: "UAVSAL_EALIGN (channel count / ld / pointer not 16-byte aligned)",
+        -3: "UAVSAL_ESHAPE (shape not supported by the kernel)",
+        -4: "UAVSAL_ESTATE (plan used in the wrong state)"}
+
+_f = C.c_void_p   # device pointers travel as integers
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("a", _f), ("lda", C.c_int32), ("a_img_stride", C.c_int64),
+                ("w", _f), ("scale", _f), ("bias", _f),
+                ("out", _f), ("ldc", C.c_int32), ("o_img_stride", C.c_int64),
+                ("res", _f), ("ldr", C.c_int32), ("r_img_stride", C.c_int64),
+                ("aux", _f), ("ldx", C.c_int32), ("x_img_stride", C.c_int64),
+                ("n_img", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("Cin", C.c_int32), ("Cout", C.c_int32), ("taps", C.c_int32),
+                ("prec", C.c_int32), ("act", C.c_int32), ("epi", C.c_int32), ("tile", C.c_int32)]
+
+
+class DwDesc(C.Structure):
+    _fields_ = [("inp", _f), ("ldi", C.c_int32), ("w9c", _f), ("scale", _f), ("bias", _f),
+                ("out", _f), ("ldo", C.c_int32),
+                ("n_img", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32),
+                ("stride", C.c_int32), ("dilation", C.c_int32), ("act", C.c_int32)]
+
+
+class StemDesc(C.Structure):
+    _fields_ = [("inp", _f), ("in_u8", _f), ("w", _f), ("scale", _f), ("bias", _f),
+                ("out", _f), ("ldo", C.c_int32),
+                ("n_img", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("mean", C.c_float * 3), ("stdv", C.c_float * 3)]
+
+
+class BilinearDesc(C.Structure):
+    _fields_ = [("inp", _f), ("ldi", C.c_int32), ("Hi", C.c_int32), ("Wi", C.c_int32),
+                ("out", _f), ("ldo", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32),
+                ("n_out", C.c_int32), ("C", C.c_int32), ("src_mod", C.c_int32), ("src_div", C.c_int32)]
+
+
+class TdiffDesc(C.Structure):
+    _fields_ = [("inp", _f), ("ldi", C.c_int32), ("out", _f), ("ldo", C.c_int32),
+                ("n_img", C.c_int32), ("HW", C.c_int32), ("C", C.c_int32), ("seq_len", C.c_int32)]
+
+
+class TsumDesc(C.Structure):
+    _fields_ = [("inp", _f), ("ldi", C.c_int32), ("out", _f), ("ldo", C.c_int32),
+                ("n_groups", C.c_int32), ("T", C.c_int32), ("HW", C.c_int32), ("C", C.c_int32)]
+
+
+class LayoutDesc(C.Structure):
+    _fields_ = [("inp", _f), ("out", _f), ("n_img", C.c_int32), ("C", C.c_int32), ("HW", C.c_int32),
+                ("ld", C.c_int32), ("to_nhwc", C.c_int32), ("Cpad", C.c_int32)]
+
+
+DESC_TYPES = [ConvDesc, DwDesc, StemDesc, BilinearDesc, TdiffDesc, TsumDesc, LayoutDesc]
+
+# every symbol include/uavsal_hip.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("uavsal_conv_gemm", C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    ("uavsal_dw3x3", C.c_int, [C.POINTER(DwDesc), C.c_void_p]),
+    ("uavsal_stem_conv", C.c_int, [C.POINTER(StemDesc), C.c_void_p]),
+    ("uavsal_bilinear_ac", C.c_int, [C.POINTER(BilinearDesc), C.c_void_p]),
+    ("uavsal_tdiff", C.c_int, [C.POINTER(TdiffDesc), C.c_void_p]),
+    ("uavsal_tsum", C.c_int, [C.POINTER(TsumDesc), C.c_void_p]),
+    ("uavsal_layout", C.c_int, [C.POINTER(LayoutDesc), C.c_void_p]),
+    ("uavsal_plan_create", C.c_void_p, []),
+    ("uavsal_plan_destroy", None, [C.c_void_p]),
+    ("uavsal_plan_add_conv", C.c_int, [C.c_void_p, C.POINTER(ConvDesc)]),
+    ("uavsal_plan_add_dw", C.c_int, [C.c_void_p, C.POINTER(DwDesc)]),
+    ("uavsal_plan_add_stem", C.c_int, [C.c_void_p, C.POINTER(StemDesc)]),
+    ("uavsal_plan_add_bilinear", C.c_int, [C.c_void_p, C.POINTER(BilinearDesc)]),
+    ("uavsal_plan_add_tdiff", C.c_int, [C.c_void_p, C.POINTER(TdiffDesc)]),
+    ("uavsal_plan_add_tsum", C.c_int, [C.c_void_p, C.POINTER(TsumDesc)]),
+    ("uavsal_plan_add_layout", C.c_int, [C.c_void_p, C.POINTER(LayoutDesc)]),
+    ("uavsal_plan_size", C.c_int, [C.c_void_p]),
+    ("uavsal_plan_run", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    ("uavsal_plan_graph_build", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("uavsal_plan_graph_launch", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("uavsal_plan_time", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_float)]),
+    ("uavsal_abi_version", C.c_int, []),
+    ("uavsal_sizeof_desc", C.c_int, [C.c_int]),
+    ("uavsal_build_info", C.c_char_p, []),
+]
+
+_lib = None
+
+
+def load():
+    """Load (once) and type the shared library.  Raises RuntimeError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libuavsal_hip.so is not built (%s). Run `python -m iip_uavsal_saliency_amd.build` "
+            "(needs hipcc). There is no CPU fallback for the UAVSal HIP path." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, res, args in SYMBOLS:
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.uavsal_abi_version() != 1:
+        raise RuntimeError("libuavsal_hip.so ABI version mismatch")
+    for i, t in enumerate(DESC_TYPES):
+        if lib.uavsal_sizeof_desc(i) != C.sizeof(t):
+            raise RuntimeError("descriptor %s: ctypes size %d != C size %d" % (
+                t.__name__, C.sizeof(t), lib.uavsal_sizeof_desc(i)))
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str = "uavsal call"):
+    if code == 0:
+        return
+    if code < 0:
+        raise RuntimeError("%s rejected its arguments: %s" % (what, _ERR.get(code, str(code))))
+    raise RuntimeError("%s failed with hipError_t %d" % (what, code))

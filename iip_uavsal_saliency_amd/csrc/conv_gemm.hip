@@ -1,0 +1,398 @@
+// Dense 1x1 / 3x3 convolution as an implicit GEMM on the CDNA4 matrix cores.
+//
+//   out[m, n] = epilogue( sum_{tap, ci} A[pixel(m) + tap offset, ci] * W[n, tap, ci] )
+//   m = output pixel (image-major, NHWC), n = output channel.
+//
+// Replaces BasicConv2d k=1/k=3 and the pw-linear conv+BN of dwBlock (reference
+// model.py:65-72, 94-95, 100-101) and ConvTWACell.forward (model_convlstm.py:276-292);
+// see include/uavsal_hip.h for the contract.
+//
+// Structure (one 256-thread workgroup = 4 wave64):
+//   * block tile BM x BN, K tile KT (16 fp32 or 32 bf16 elements = one 64-byte row of a
+//     panel).  A "panel" is rows x 64 B in LDS; a row holds four 16-byte chunks, chunk c
+//     stored at slot c ^ ((row >> 2) & 3) so that the ds_read_b128 fragment reads of 32
+//     different rows are bank-conflict free (guide: LDS XOR swizzle, T2).
+//   * global -> registers -> LDS staging, double buffered: tile k+1's global loads are
+//     issued before tile k's MFMAs and written to the other LDS stage after them
+//     (issue-early / write-late, one barrier per K tile).
+//   * fp32 activations are converted while staging: F32 keeps them, BF16 rounds to bf16,
+//     BF16X3 splits x = hi + lo (two bf16) and issues hi*hi + hi*lo + lo*hi, i.e. ~16
+//     mantissa bits at 3/16 of the fp32-MFMA cost.
+//   * per K sub-step each lane reads ONE 16-byte chunk per 32-row fragment: for the
+//     bf16 MFMA (32x32x16) that is its 8 k-values; for the fp32 MFMA (32x32x2) the 4
+//     floats feed 4 consecutive MFMAs (lanes 0-31 take chunk 2s, lanes 32-63 chunk
+//     2s+1 -- any k permutation is legal as long as A and B agree).
+//   * epilogue straight from the accumulators (C/D layout: col = lane & 31,
+//     row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)): folded BN, ReLU6 / sigmoid,
+//     residual add, channel-slice store, or the ConvTWA gate + convex state update.
+//   * blockIdx is remapped so that each XCD (private L2) owns a contiguous range of
+//     (M tile, N tile) pairs: the N tiles that re-read one activation tile run on the
+//     same L2.
+#include "common.h"
+
+namespace {
+
+struct ConvK {
+    const float* a;
+    const char* w;
+    const float* scale;
+    const float* bias;
+    float* out;
+    const float* res;
+    const float* aux;
+    long long a_is, o_is, r_is, x_is;
+    int lda, ldc, ldr, ldx;
+    int M, HW, H, W, Cin, Cout, Kpad, Npad, ktiles, act, epi;
+    int tiles_n, nblk, contig;
+};
+
+__device__ __forceinline__ long long row_off(int m, int HW, long long img_stride, int contig) {
+    if (contig) return m;
+    const int img = m / HW;
+    return (long long)img * img_stride + (m - img * HW);
+}
+
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 v = {a, b};
+    bf2 r = __builtin_convertvector(v, bf2);
+    return __builtin_bit_cast(unsigned, r);
+}
+
+__device__ __forceinline__ float bf16_hi_as_f32(float x) {
+    // value of bf16(x) as fp32 (round to nearest even), via the same conversion as the pack
+    __bf16 h = (__bf16)x;
+    return (float)h;
+}
+
+template <int PREC, int WAVES_M, int WAVES_N, int WM, int WN, int TAPS>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvK p) {
+    constexpr int BM = WAVES_M * WM * 32;
+    constexpr int BN = WAVES_N * WN * 32;
+    constexpr int KT = (PREC == UAVSAL_PREC_F32) ? 16 : 32;
+    constexpr int NPAN = (PREC == UAVSAL_PREC_BF16X3) ? 2 : 1;
+    constexpr int NLD = (PREC == UAVSAL_PREC_F32) ? 1 : 2;   // float4 loads per A chunk
+    constexpr int A_IT = (BM * 4) / 256;
+    constexpr int B_IT = (BN * 4 + 255) / 256;
+    constexpr int APAN = BM * 64;
+    constexpr int BPAN = BN * 64;
+    constexpr int STAGE = NPAN * (APAN + BPAN);
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+    static_assert((BM * 4) % 256 == 0, "A tile must divide over 256 threads");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int v = xcd_virtual_block(blockIdx.x, p.nblk);
+    const int tile_m = v / p.tiles_n;
+    const int tile_n = v - tile_m * p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    // ---- per-thread staging coordinates ------------------------------------------------
+    const int ch = tid & 3;              // 16-byte chunk within the 64-byte panel row
+    long long a_base[A_IT];
+    int a_y[A_IT], a_x[A_IT];
+    bool a_ok[A_IT];
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+        const int row = (tid >> 2) + it * 64;
+        const int m = m0 + row;
+        a_ok[it] = m < p.M;
+        const int mm = a_ok[it] ? m : 0;
+        if (TAPS == 1) {
+            a_base[it] = row_off(mm, p.HW, p.a_is, p.contig) * p.lda;
+            a_y[it] = 0; a_x[it] = 0;
+        } else {
+            const int img = mm / p.HW;
+            const int pix = mm - img * p.HW;
+            a_y[it] = pix / p.W;
+            a_x[it] = pix - a_y[it] * p.W;
+            a_base[it] = (long long)img * p.a_is;   // in pixels; tap offset added per tile
+        }
+    }
+    const int b_row0 = tid >> 2;
+
+    f32x4 a_reg[A_IT][NLD];
+    u32x4 b_reg[B_IT][NPAN];
+
+    auto load_tile = [&](int kt) {
+        int ci0 = kt * KT;
+        int dy = 0, dx = 0;
+        if (TAPS == 9) {
+            const int tap = ci0 / p.Cin;
+            ci0 -= tap * p.Cin;
+            dy = tap / 3 - 1;
+            dx = tap - (tap / 3) * 3 - 1;
+        }
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            bool ok = a_ok[it];
+            long long off;
+            if (TAPS == 1) {
+                off = a_base[it];
+            } else {
+                const int yy = a_y[it] + dy, xx = a_x[it] + dx;
+                ok = ok && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+                off = (a_base[it] + (long long)yy * p.W + xx) * p.lda;
+            }
+#pragma unroll
+            for (int l = 0; l < NLD; ++l) {
+                const int kk = ci0 + ch * 4 + l * 16;
+                const bool okk = ok && kk < p.Cin;
+                f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                a_reg[it][l] = okk ? *reinterpret_cast<const f32x4*>(p.a + off + kk) : z;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            const int row = b_row0 + it * 64;
+            const int nn = n0 + row;
+            const bool ok = (row < BN) && (nn < p.Npad);
+#pragma unroll
+            for (int pn = 0; pn < NPAN; ++pn) {
+                u32x4 z = {0u, 0u, 0u, 0u};
+                if (ok) {
+                    const size_t esz = (PREC == UAVSAL_PREC_F32) ? 4 : 2;
+                    const size_t elem = ((size_t)pn * p.Npad + nn) * p.Kpad + (size_t)kt * KT;
+                    z = *reinterpret_cast<const u32x4*>(p.w + elem * esz + ch * 16);
+                }
+                b_reg[it][pn] = z;
+            }
+        }
+    };
+
+    auto store_tile = [&](int stage) {
+        char* As = smem + stage * STAGE;
+        char* Bs = As + NPAN * APAN;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const int row = (tid >> 2) + it * 64;
+            const int slot = (row * 4 + (ch ^ ((row >> 2) & 3))) * 16;
+            if (PREC == UAVSAL_PREC_F32) {
+                *reinterpret_cast<f32x4*>(As + slot) = a_reg[it][0];
+            } else {
+                const f32x4 x0 = a_reg[it][0], x1 = a_reg[it][NLD - 1];
+                u32x4 hi;
+                hi.x = pack_bf16x2(x0.x, x0.y); hi.y = pack_bf16x2(x0.z, x0.w);
+                hi.z = pack_bf16x2(x1.x, x1.y); hi.w = pack_bf16x2(x1.z, x1.w);
+                *reinterpret_cast<u32x4*>(As + slot) = hi;
+                if (PREC == UAVSAL_PREC_BF16X3) {
+                    u32x4 lo;
+                    lo.x = pack_bf16x2(x0.x - bf16_hi_as_f32(x0.x), x0.y - bf16_hi_as_f32(x0.y));
+                    lo.y = pack_bf16x2(x0.z - bf16_hi_as_f32(x0.z), x0.w - bf16_hi_as_f32(x0.w));
+                    lo.z = pack_bf16x2(x1.x - bf16_hi_as_f32(x1.x), x1.y - bf16_hi_as_f32(x1.y));
+                    lo.w = pack_bf16x2(x1.z - bf16_hi_as_f32(x1.z), x1.w - bf16_hi_as_f32(x1.w));
+                    *reinterpret_cast<u32x4*>(As + APAN + slot) = lo;
+                }
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            const int row = b_row0 + it * 64;
+            if (row < BN) {
+                const int slot = (row * 4 + (ch ^ ((row >> 2) & 3))) * 16;
+#pragma unroll
+                for (int pn = 0; pn < NPAN; ++pn)
+                    *reinterpret_cast<u32x4*>(Bs + pn * BPAN + slot) = b_reg[it][pn];
+            }
+        }
+    };
+
+    // ---- accumulators ----------------------------------------------------------------
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
+
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
+    const int lr = lane & 31, lh = lane >> 5;
+
+    auto compute = [&](int stage) {
+        const char* As = smem + stage * STAGE;
+        const char* Bs = As + NPAN * APAN;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int chunk = 2 * s + lh;
+            u32x4 af[WM][NPAN], bfr[WN][NPAN];
+#pragma unroll
+            for (int i = 0; i < WM; ++i) {
+                const int row = (wm * WM + i) * 32 + lr;
+                const int slot = (row * 4 + (chunk ^ ((row >> 2) & 3))) * 16;
+#pragma unroll
+                for (int pn = 0; pn < NPAN; ++pn)
+                    af[i][pn] = *reinterpret_cast<const u32x4*>(As + pn * APAN + slot);
+            }
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                const int row = (wn * WN + j) * 32 + lr;
+                const int slot = (row * 4 + (chunk ^ ((row >> 2) & 3))) * 16;
+#pragma unroll
+                for (int pn = 0; pn < NPAN; ++pn)
+                    bfr[j][pn] = *reinterpret_cast<const u32x4*>(Bs + pn * BPAN + slot);
+            }
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) {
+                    if (PREC == UAVSAL_PREC_F32) {
+                        const f32x4 av = __builtin_bit_cast(f32x4, af[i][0]);
+                        const f32x4 bv = __builtin_bit_cast(f32x4, bfr[j][0]);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[i][j], 0, 0, 0);
+                    } else {
+                        const bf16x8 ah = __builtin_bit_cast(bf16x8, af[i][0]);
+                        const bf16x8 bh = __builtin_bit_cast(bf16x8, bfr[j][0]);
+                        if (PREC == UAVSAL_PREC_BF16X3) {
+                            const bf16x8 al = __builtin_bit_cast(bf16x8, af[i][NPAN - 1]);
+                            const bf16x8 bl = __builtin_bit_cast(bf16x8, bfr[j][NPAN - 1]);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i][j], 0, 0, 0);
+                        }
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i][j], 0, 0, 0);
+                    }
+                }
+        }
+    };
+
+    // ---- main loop ---------------------------------------------------------------------
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < p.ktiles; ++kt) {
+        const int cur = kt & 1;
+        const bool more = (kt + 1) < p.ktiles;
+        if (more) load_tile(kt + 1);
+        compute(cur);
+        if (more) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue ----------------------------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const int m = m0 + (wm * WM + i) * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
+            if (m >= p.M) continue;
+            const long long oo = row_off(m, p.HW, p.o_is, p.contig) * p.ldc;
+            long long ro = 0, xo = 0, ao = 0;
+            if (p.res) ro = row_off(m, p.HW, p.r_is, p.contig) * p.ldr;
+            if (p.epi == UAVSAL_EPI_TWA) {
+                xo = row_off(m, p.HW, p.x_is, p.contig) * p.ldx;
+                ao = row_off(m, p.HW, p.a_is, p.contig) * p.lda;
+            }
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                const int n = n0 + (wn * WN + j) * 32 + lr;
+                if (n >= p.Cout) continue;
+                float vv = acc[i][j][g];
+                if (p.epi == UAVSAL_EPI_TWA) {
+                    const float z = vv + p.aux[xo + n];
+                    const float gate = 1.f / (1.f + expf(-z));
+                    const float xt = p.res[ro + n];
+                    const float hp = p.a[ao + n];
+                    vv = gate * xt + (1.f - gate) * hp;
+                } else {
+                    if (p.scale) vv = vv * p.scale[n] + p.bias[n];
+                    vv = apply_act(vv, p.act);
+                    if (p.res) vv += p.res[ro + n];
+                }
+                p.out[oo + n] = vv;
+            }
+        }
+    }
+}
+
+template <int PREC, int WAVES_M, int WAVES_N, int WM, int WN>
+int launch_variant(const ConvK& k0, int taps, hipStream_t stream) {
+    constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32;
+    constexpr int NPAN = (PREC == UAVSAL_PREC_BF16X3) ? 2 : 1;
+    constexpr int SMEM = 2 * NPAN * (BM + BN) * 64;
+    ConvK k = k0;
+    const int tiles_m = (k.M + BM - 1) / BM;
+    k.tiles_n = (k.Cout + BN - 1) / BN;
+    k.nblk = tiles_m * k.tiles_n;
+    if (taps == 1)
+        hipLaunchKernelGGL((conv_gemm_kernel<PREC, WAVES_M, WAVES_N, WM, WN, 1>), dim3(k.nblk), dim3(256), SMEM, stream, k);
+    else
+        hipLaunchKernelGGL((conv_gemm_kernel<PREC, WAVES_M, WAVES_N, WM, WN, 9>), dim3(k.nblk), dim3(256), SMEM, stream, k);
+    return uavsal_launch_status();
+}
+
+template <int PREC>
+int launch_prec(const ConvK& k, int taps, int tile, hipStream_t stream) {
+    switch (tile) {
+        case 1: return launch_variant<PREC, 2, 2, 2, 2>(k, taps, stream);   // 128 x 128
+        case 2: return launch_variant<PREC, 4, 1, 1, 2>(k, taps, stream);   // 128 x 64
+        case 3: return launch_variant<PREC, 4, 1, 1, 1>(k, taps, stream);   // 128 x 32
+        default: return launch_variant<PREC, 2, 2, 1, 1>(k, taps, stream);  // 64 x 64
+    }
+}
+
+int pick_tile(long long M, int Cout) {
+    // largest tile that still gives every CU (256) about two workgroups; N tile no wider
+    // than the (32-padded) channel count needs
+    const int npad = (Cout + 31) / 32 * 32;
+    if (npad <= 32) return 3;
+    const int cand_bm[4] = {128, 128, 128, 64};
+    const int cand_bn[4] = {128, 64, 32, 64};
+    for (int t = 0; t < 4; ++t) {
+        if (cand_bn[t] > npad) continue;      // don't waste N
+        const long long blocks = ((M + cand_bm[t] - 1) / cand_bm[t]) * ((Cout + cand_bn[t] - 1) / cand_bn[t]);
+        if (blocks >= 512) return t + 1;
+    }
+    return 4;
+}
+
+}  // namespace
+
+extern "C" int uavsal_conv_gemm(const uavsal_conv_desc* d, uavsal_stream_t stream) {
+    if (!d || !d->a || !d->w || !d->out) return UAVSAL_EINVAL;
+    if (d->n_img <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0) return UAVSAL_EINVAL;
+    if (d->taps != 1 && d->taps != 9) return UAVSAL_ESHAPE;
+    if (d->prec < 0 || d->prec > 2) return UAVSAL_ESHAPE;
+    if ((d->Cin & 3) || (d->lda & 3) || d->lda < d->Cin) return UAVSAL_EALIGN;
+    if (d->ldc < d->Cout) return UAVSAL_ESHAPE;
+    if (!uavsal_aligned16(d->a) || !uavsal_aligned16(d->w)) return UAVSAL_EALIGN;
+    if (d->taps == 9 && (d->Cin % 32)) return UAVSAL_ESHAPE;
+    if ((d->scale == nullptr) != (d->bias == nullptr)) return UAVSAL_EINVAL;
+    if (d->res && d->ldr < d->Cout) return UAVSAL_ESHAPE;
+    if (d->epi == UAVSAL_EPI_TWA) {
+        if (!d->res || !d->aux || d->Cin != d->Cout || d->ldx < d->Cout) return UAVSAL_ESHAPE;
+    } else if (d->epi != UAVSAL_EPI_AFFINE) {
+        return UAVSAL_ESHAPE;
+    }
+    const long long HW = (long long)d->H * d->W;
+    const long long M = HW * d->n_img;
+    if (M > 0x7fffffffLL) return UAVSAL_ESHAPE;
+    if (d->a_img_stride < HW || d->o_img_stride < HW) return UAVSAL_ESHAPE;
+
+    ConvK k;
+    k.a = d->a; k.w = (const char*)d->w; k.scale = d->scale; k.bias = d->bias;
+    k.out = d->out; k.res = d->res; k.aux = d->aux;
+    k.a_is = d->a_img_stride; k.o_is = d->o_img_stride;
+    k.r_is = d->res ? d->r_img_stride : HW; k.x_is = d->aux ? d->x_img_stride : HW;
+    k.lda = d->lda; k.ldc = d->ldc; k.ldr = d->ldr; k.ldx = d->ldx;
+    k.M = (int)M; k.HW = (int)HW; k.H = d->H; k.W = d->W; k.Cin = d->Cin; k.Cout = d->Cout;
+    const int KT = d->prec == UAVSAL_PREC_F32 ? 16 : 32;
+    k.Kpad = (d->taps * d->Cin + KT - 1) / KT * KT;
+    k.Npad = (d->Cout + 31) / 32 * 32;
+    k.ktiles = k.Kpad / KT;
+    k.act = d->act; k.epi = d->epi;
+    k.contig = (k.a_is == HW && k.o_is == HW && k.r_is == HW && k.x_is == HW) ? 1 : 0;
+    k.tiles_n = 0; k.nblk = 0;
+    const int tile = (d->tile >= 1 && d->tile <= 4) ? d->tile : pick_tile(M, d->Cout);
+    hipStream_t s = (hipStream_t)stream;
+    switch (d->prec) {
+        case UAVSAL_PREC_F32: return launch_prec<UAVSAL_PREC_F32>(k, d->taps, tile, s);
+        case UAVSAL_PREC_BF16X3: return launch_prec<UAVSAL_PREC_BF16X3>(k, d->taps, tile, s);
+        default: return launch_prec<UAVSAL_PREC_BF16>(k, d->taps, tile, s);
+    }
+}

@@ -1,0 +1,255 @@
+// Small memory-bound kernels around the convolutions: the 3->32 stride-2 stem reading the
+// caller's NCHW frames, align_corners bilinear resize into channel slices, the temporal
+// neighbour differences of teConv_sub, the per-chunk time sum of the context prior and the
+// NCHW <-> NHWC layout changes at the call boundary.  Reference lines: see uavsal_hip.h.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------- stem 3x3 s2, 3 -> 32
+struct StemK {
+    const float* in; const uint8_t* in_u8; const float* w; const float* scale; const float* bias;
+    float* out; int ldo, H, W, Ho, Wo; long long total;
+    float mean[3], stdv[3];
+};
+
+__global__ __launch_bounds__(256) void stem_kernel(const StemK p) {
+    __shared__ float wsh[27 * 32];
+    __shared__ float ssh[32], bsh[32];
+    for (int i = threadIdx.x; i < 27 * 32; i += 256) wsh[i] = p.w[i];
+    if (threadIdx.x < 32) { ssh[threadIdx.x] = p.scale[threadIdx.x]; bsh[threadIdx.x] = p.bias[threadIdx.x]; }
+    __syncthreads();
+    const long long item = (long long)blockIdx.x * 256 + threadIdx.x;   // (pixel, group of 8 channels)
+    if (item >= p.total) return;
+    const int g = (int)(item & 3);
+    long long pix = item >> 2;
+    const int ox = (int)(pix % p.Wo); pix /= p.Wo;
+    const int oy = (int)(pix % p.Ho);
+    const int n = (int)(pix / p.Ho);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    const size_t plane = (size_t)p.H * p.W;
+#pragma unroll
+    for (int ci = 0; ci < 3; ++ci) {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy * 2 - 1 + ky;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox * 2 - 1 + kx;
+                float v = 0.f;
+                if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+                    const size_t idx = ((size_t)n * 3 + ci) * plane + (size_t)iy * p.W + ix;
+                    if (p.in_u8) v = ((float)p.in_u8[idx] / 255.0f - p.mean[ci]) / p.stdv[ci];
+                    else v = p.in[idx];
+                }
+                const float* wr = wsh + (ci * 9 + ky * 3 + kx) * 32 + g * 8;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = fmaf(v, wr[j], acc[j]);
+            }
+        }
+    }
+    float* o = p.out + (((size_t)n * p.Ho + oy) * p.Wo + ox) * p.ldo + g * 8;
+    f32x4 r0, r1;
+    float r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = fminf(fmaxf(acc[j] * ssh[g * 8 + j] + bsh[g * 8 + j], 0.f), 6.f);
+    r0 = (f32x4){r[0], r[1], r[2], r[3]}; r1 = (f32x4){r[4], r[5], r[6], r[7]};
+    *reinterpret_cast<f32x4*>(o) = r0;
+    *reinterpret_cast<f32x4*>(o + 4) = r1;
+}
+
+// ---------------------------------------------------------------- bilinear, align_corners=True
+struct BilK {
+    const float* in; float* out;
+    int ldi, ldo, Hi, Wi, Ho, Wo, C4, src_mod, src_div;
+    float sy, sx; long long total;
+};
+
+__global__ __launch_bounds__(256) void bilinear_kernel(const BilK p) {
+    const long long item = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (item >= p.total) return;
+    const int c = (int)(item % p.C4) * 4;
+    long long t = item / p.C4;
+    const int ox = (int)(t % p.Wo); t /= p.Wo;
+    const int oy = (int)(t % p.Ho);
+    const int n = (int)(t / p.Ho);
+    const int ns = (n % p.src_mod) / p.src_div;
+    // ATen upsample_bilinear2d (align_corners): src = scale * dst, scale = (in-1)/(out-1)
+    const float fy = p.sy * oy, fx = p.sx * ox;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < p.Hi - 1 ? 1 : 0), x1 = x0 + (x0 < p.Wi - 1 ? 1 : 0);
+    const float ly = fy - y0, lx = fx - x0;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const float* b = p.in + (size_t)ns * p.Hi * p.Wi * p.ldi + c;
+    const f32x4 v00 = *reinterpret_cast<const f32x4*>(b + ((size_t)y0 * p.Wi + x0) * p.ldi);
+    const f32x4 v01 = *reinterpret_cast<const f32x4*>(b + ((size_t)y0 * p.Wi + x1) * p.ldi);
+    const f32x4 v10 = *reinterpret_cast<const f32x4*>(b + ((size_t)y1 * p.Wi + x0) * p.ldi);
+    const f32x4 v11 = *reinterpret_cast<const f32x4*>(b + ((size_t)y1 * p.Wi + x1) * p.ldi);
+    const f32x4 r = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+    *reinterpret_cast<f32x4*>(p.out + (((size_t)n * p.Ho + oy) * p.Wo + ox) * p.ldo + c) = r;
+}
+
+// ---------------------------------------------------------------- temporal differences
+struct TdK { const float* in; float* out; int ldi, ldo, HW, C4, L; long long total; };
+
+__global__ __launch_bounds__(256) void tdiff_kernel(const TdK p) {
+    const long long item = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (item >= p.total) return;
+    const int c = (int)(item % p.C4) * 4;
+    long long t = item / p.C4;
+    const int pix = (int)(t % p.HW);
+    const int n = (int)(t / p.HW);
+    const int tt = n % p.L;
+    const size_t img = (size_t)p.HW * p.ldi;
+    const float* cur = p.in + (size_t)n * img + (size_t)pix * p.ldi + c;
+    const f32x4 x = *reinterpret_cast<const f32x4*>(cur);
+    f32x4 dprev, dnext;
+    if (tt == 0) {
+        const f32x4 nx = *reinterpret_cast<const f32x4*>(cur + img);
+        dprev = nx - x; dnext = x - nx;                       // model.py:194
+    } else if (tt == p.L - 1) {
+        const f32x4 pv = *reinterpret_cast<const f32x4*>(cur - img);
+        dprev = x - pv; dnext = pv - x;                       // model.py:198
+    } else {
+        const f32x4 pv = *reinterpret_cast<const f32x4*>(cur - img);
+        const f32x4 nx = *reinterpret_cast<const f32x4*>(cur + img);
+        dprev = x - pv; dnext = x - nx;                       // model.py:196
+    }
+    float* o = p.out + ((size_t)n * p.HW + pix) * p.ldo + c;
+    *reinterpret_cast<f32x4*>(o) = dprev;
+    *reinterpret_cast<f32x4*>(o + p.C4 * 4) = dnext;
+}
+
+// ---------------------------------------------------------------- sum over T images
+struct TsK { const float* in; float* out; int ldi, ldo, HW, C4, T; long long total; };
+
+__global__ __launch_bounds__(256) void tsum_kernel(const TsK p) {
+    const long long item = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (item >= p.total) return;
+    const int c = (int)(item % p.C4) * 4;
+    long long t = item / p.C4;
+    const int pix = (int)(t % p.HW);
+    const int b = (int)(t / p.HW);
+    const size_t img = (size_t)p.HW * p.ldi;
+    const float* src = p.in + (size_t)b * p.T * img + (size_t)pix * p.ldi + c;
+    f32x4 s = *reinterpret_cast<const f32x4*>(src);
+    for (int k = 1; k < p.T; ++k) s += *reinterpret_cast<const f32x4*>(src + (size_t)k * img);
+    *reinterpret_cast<f32x4*>(p.out + ((size_t)b * p.HW + pix) * p.ldo + c) = s;
+}
+
+// ---------------------------------------------------------------- NCHW <-> NHWC
+struct LayK { const float* in; float* out; int C, HW, ld, Cpad, to_nhwc; long long total; };
+
+__global__ __launch_bounds__(256) void layout_kernel(const LayK p) {
+    // 32x32 (pixel x channel) tile transposed through LDS so both sides stay coalesced
+    __shared__ float tile[32][33];
+    const int tiles_c = (p.Cpad + 31) / 32;
+    const int tiles_p = (p.HW + 31) / 32;
+    long long b = blockIdx.x;
+    const int tc = (int)(b % tiles_c); b /= tiles_c;
+    const int tp = (int)(b % tiles_p);
+    const int n = (int)(b / tiles_p);
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;   // 32 x 8
+    if (p.to_nhwc) {
+        for (int j = ly; j < 32; j += 8) {        // read: channel tc*32+j, pixels contiguous
+            const int c = tc * 32 + j, px = tp * 32 + lx;
+            tile[j][lx] = (c < p.C && px < p.HW) ? p.in[((size_t)n * p.C + c) * p.HW + px] : 0.f;
+        }
+        __syncthreads();
+        for (int j = ly; j < 32; j += 8) {        // write: pixel tp*32+j, channels contiguous
+            const int px = tp * 32 + j, c = tc * 32 + lx;
+            if (px < p.HW && c < p.Cpad) p.out[((size_t)n * p.HW + px) * p.ld + c] = tile[lx][j];
+        }
+    } else {
+        for (int j = ly; j < 32; j += 8) {
+            const int px = tp * 32 + j, c = tc * 32 + lx;
+            tile[j][lx] = (px < p.HW && c < p.C) ? p.in[((size_t)n * p.HW + px) * p.ld + c] : 0.f;
+        }
+        __syncthreads();
+        for (int j = ly; j < 32; j += 8) {
+            const int c = tc * 32 + j, px = tp * 32 + lx;
+            if (c < p.C && px < p.HW) p.out[((size_t)n * p.C + c) * p.HW + px] = tile[lx][j];
+        }
+    }
+}
+
+inline int grid_for(long long total, int* nblk) {
+    const long long b = (total + 255) / 256;
+    if (b <= 0 || b > 0x7fffffffLL) return UAVSAL_ESHAPE;
+    *nblk = (int)b;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int uavsal_stem_conv(const uavsal_stem_desc* d, uavsal_stream_t stream) {
+    if (!d || (!d->in && !d->in_u8) || !d->w || !d->scale || !d->bias || !d->out) return UAVSAL_EINVAL;
+    if (d->n_img <= 0 || d->H <= 0 || d->W <= 0) return UAVSAL_EINVAL;
+    if ((d->ldo & 3) || d->ldo < 32 || !uavsal_aligned16(d->out)) return UAVSAL_EALIGN;
+    StemK k;
+    k.in = d->in; k.in_u8 = d->in_u8; k.w = d->w; k.scale = d->scale; k.bias = d->bias; k.out = d->out;
+    k.ldo = d->ldo; k.H = d->H; k.W = d->W; k.Ho = (d->H - 1) / 2 + 1; k.Wo = (d->W - 1) / 2 + 1;
+    for (int i = 0; i < 3; ++i) { k.mean[i] = d->mean[i]; k.stdv[i] = d->stdv[i]; }
+    k.total = (long long)d->n_img * k.Ho * k.Wo * 4;
+    int nblk; int e = grid_for(k.total, &nblk); if (e) return e;
+    hipLaunchKernelGGL(stem_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, k);
+    return uavsal_launch_status();
+}
+
+extern "C" int uavsal_bilinear_ac(const uavsal_bilinear_desc* d, uavsal_stream_t stream) {
+    if (!d || !d->in || !d->out) return UAVSAL_EINVAL;
+    if (d->n_out <= 0 || d->C <= 0 || d->Hi <= 0 || d->Wi <= 0 || d->Ho <= 0 || d->Wo <= 0) return UAVSAL_EINVAL;
+    if (d->src_mod <= 0 || d->src_div <= 0) return UAVSAL_EINVAL;
+    if ((d->C & 3) || (d->ldi & 3) || (d->ldo & 3) || d->ldi < d->C || d->ldo < d->C) return UAVSAL_EALIGN;
+    if (!uavsal_aligned16(d->in) || !uavsal_aligned16(d->out)) return UAVSAL_EALIGN;
+    BilK k;
+    k.in = d->in; k.out = d->out; k.ldi = d->ldi; k.ldo = d->ldo;
+    k.Hi = d->Hi; k.Wi = d->Wi; k.Ho = d->Ho; k.Wo = d->Wo; k.C4 = d->C / 4;
+    k.src_mod = d->src_mod; k.src_div = d->src_div;
+    k.sy = d->Ho > 1 ? (float)(d->Hi - 1) / (float)(d->Ho - 1) : 0.f;
+    k.sx = d->Wo > 1 ? (float)(d->Wi - 1) / (float)(d->Wo - 1) : 0.f;
+    k.total = (long long)d->n_out * d->Ho * d->Wo * k.C4;
+    int nblk; int e = grid_for(k.total, &nblk); if (e) return e;
+    hipLaunchKernelGGL(bilinear_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, k);
+    return uavsal_launch_status();
+}
+
+extern "C" int uavsal_tdiff(const uavsal_tdiff_desc* d, uavsal_stream_t stream) {
+    if (!d || !d->in || !d->out) return UAVSAL_EINVAL;
+    if (d->n_img <= 0 || d->HW <= 0 || d->C <= 0) return UAVSAL_EINVAL;
+    if (d->seq_len < 2 || (d->n_img % d->seq_len)) return UAVSAL_ESHAPE;   // reference raises on 1 frame
+    if ((d->C & 3) || (d->ldi & 3) || (d->ldo & 3) || d->ldi < d->C || d->ldo < 2 * d->C) return UAVSAL_EALIGN;
+    if (!uavsal_aligned16(d->in) || !uavsal_aligned16(d->out)) return UAVSAL_EALIGN;
+    TdK k; k.in = d->in; k.out = d->out; k.ldi = d->ldi; k.ldo = d->ldo; k.HW = d->HW; k.C4 = d->C / 4; k.L = d->seq_len;
+    k.total = (long long)d->n_img * d->HW * k.C4;
+    int nblk; int e = grid_for(k.total, &nblk); if (e) return e;
+    hipLaunchKernelGGL(tdiff_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, k);
+    return uavsal_launch_status();
+}
+
+extern "C" int uavsal_tsum(const uavsal_tsum_desc* d, uavsal_stream_t stream) {
+    if (!d || !d->in || !d->out) return UAVSAL_EINVAL;
+    if (d->n_groups <= 0 || d->T <= 0 || d->HW <= 0 || d->C <= 0) return UAVSAL_EINVAL;
+    if ((d->C & 3) || (d->ldi & 3) || (d->ldo & 3) || d->ldi < d->C || d->ldo < d->C) return UAVSAL_EALIGN;
+    if (!uavsal_aligned16(d->in) || !uavsal_aligned16(d->out)) return UAVSAL_EALIGN;
+    TsK k; k.in = d->in; k.out = d->out; k.ldi = d->ldi; k.ldo = d->ldo; k.HW = d->HW; k.C4 = d->C / 4; k.T = d->T;
+    k.total = (long long)d->n_groups * d->HW * k.C4;
+    int nblk; int e = grid_for(k.total, &nblk); if (e) return e;
+    hipLaunchKernelGGL(tsum_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, k);
+    return uavsal_launch_status();
+}
+
+extern "C" int uavsal_layout(const uavsal_layout_desc* d, uavsal_stream_t stream) {
+    if (!d || !d->in || !d->out) return UAVSAL_EINVAL;
+    if (d->n_img <= 0 || d->C <= 0 || d->HW <= 0) return UAVSAL_EINVAL;
+    const int cpad = d->to_nhwc ? (d->Cpad > d->C ? d->Cpad : d->C) : d->C;
+    if (d->ld < cpad) return UAVSAL_ESHAPE;
+    LayK k; k.in = d->in; k.out = d->out; k.C = d->C; k.HW = d->HW; k.ld = d->ld; k.Cpad = cpad; k.to_nhwc = d->to_nhwc;
+    const long long nb = (long long)d->n_img * ((d->HW + 31) / 32) * ((cpad + 31) / 32);
+    if (nb > 0x7fffffffLL) return UAVSAL_ESHAPE;
+    k.total = nb;
+    hipLaunchKernelGGL(layout_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, k);
+    return uavsal_launch_status();
+}

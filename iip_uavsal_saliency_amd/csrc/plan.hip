@@ -1,0 +1,147 @@
+// Native launch plan: the host side records the ~150 kernel launches of one
+// UAVSal.forward once (descriptors with resolved device pointers), then replays them
+// from C++ -- either as a plain launch loop or as one captured hipGraph -- so the per-call
+// Python / ctypes overhead is a single call.  Also hosts the hipEvent timing used by
+// bench.py (events recorded on the same stream the kernels are launched on).
+#include <vector>
+#include <new>
+#include "common.h"
+
+namespace {
+enum OpKind { OP_CONV = 0, OP_DW, OP_STEM, OP_BILINEAR, OP_TDIFF, OP_TSUM, OP_LAYOUT };
+
+struct Op {
+    int kind;
+    union {
+        uavsal_conv_desc conv;
+        uavsal_dw_desc dw;
+        uavsal_stem_desc stem;
+        uavsal_bilinear_desc bil;
+        uavsal_tdiff_desc td;
+        uavsal_tsum_desc ts;
+        uavsal_layout_desc lay;
+    } u;
+};
+
+int run_op(const Op& op, uavsal_stream_t s) {
+    switch (op.kind) {
+        case OP_CONV: return uavsal_conv_gemm(&op.u.conv, s);
+        case OP_DW: return uavsal_dw3x3(&op.u.dw, s);
+        case OP_STEM: return uavsal_stem_conv(&op.u.stem, s);
+        case OP_BILINEAR: return uavsal_bilinear_ac(&op.u.bil, s);
+        case OP_TDIFF: return uavsal_tdiff(&op.u.td, s);
+        case OP_TSUM: return uavsal_tsum(&op.u.ts, s);
+        case OP_LAYOUT: return uavsal_layout(&op.u.lay, s);
+    }
+    return UAVSAL_EINVAL;
+}
+}  // namespace
+
+struct uavsal_plan {
+    std::vector<Op> ops;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+};
+
+extern "C" uavsal_plan* uavsal_plan_create(void) { return new (std::nothrow) uavsal_plan(); }
+
+extern "C" void uavsal_plan_destroy(uavsal_plan* p) {
+    if (!p) return;
+    if (p->exec) hipGraphExecDestroy(p->exec);
+    if (p->graph) hipGraphDestroy(p->graph);
+    delete p;
+}
+
+#define UAVSAL_ADD(fn, KIND, field, T)                                   \
+    extern "C" int fn(uavsal_plan* p, const T* d) {                      \
+        if (!p || !d) return UAVSAL_EINVAL;                              \
+        if (p->exec) return UAVSAL_ESTATE;                               \
+        Op op; op.kind = KIND; op.u.field = *d;                          \
+        p->ops.push_back(op);                                            \
+        return (int)p->ops.size() - 1;                                   \
+    }
+UAVSAL_ADD(uavsal_plan_add_conv, OP_CONV, conv, uavsal_conv_desc)
+UAVSAL_ADD(uavsal_plan_add_dw, OP_DW, dw, uavsal_dw_desc)
+UAVSAL_ADD(uavsal_plan_add_stem, OP_STEM, stem, uavsal_stem_desc)
+UAVSAL_ADD(uavsal_plan_add_bilinear, OP_BILINEAR, bil, uavsal_bilinear_desc)
+UAVSAL_ADD(uavsal_plan_add_tdiff, OP_TDIFF, td, uavsal_tdiff_desc)
+UAVSAL_ADD(uavsal_plan_add_tsum, OP_TSUM, ts, uavsal_tsum_desc)
+UAVSAL_ADD(uavsal_plan_add_layout, OP_LAYOUT, lay, uavsal_layout_desc)
+
+extern "C" int uavsal_plan_size(const uavsal_plan* p) { return p ? (int)p->ops.size() : UAVSAL_EINVAL; }
+
+extern "C" int uavsal_plan_run(uavsal_plan* p, int first, int last, uavsal_stream_t stream) {
+    if (!p) return UAVSAL_EINVAL;
+    const int n = (int)p->ops.size();
+    if (last < 0 || last > n) last = n;
+    if (first < 0 || first > last) return UAVSAL_EINVAL;
+    for (int i = first; i < last; ++i) {
+        const int e = run_op(p->ops[i], stream);
+        if (e) return e;
+    }
+    return 0;
+}
+
+extern "C" int uavsal_plan_graph_build(uavsal_plan* p, uavsal_stream_t stream) {
+    if (!p) return UAVSAL_EINVAL;
+    if (p->exec) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) return (int)e;
+    const int r = uavsal_plan_run(p, 0, -1, stream);
+    hipGraph_t g = nullptr;
+    e = hipStreamEndCapture(s, &g);
+    if (r) { if (g) hipGraphDestroy(g); return r; }
+    if (e != hipSuccess) return (int)e;
+    hipGraphExec_t ex = nullptr;
+    e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+    if (e != hipSuccess) { hipGraphDestroy(g); return (int)e; }
+    p->graph = g; p->exec = ex;
+    return 0;
+}
+
+extern "C" int uavsal_plan_graph_launch(uavsal_plan* p, uavsal_stream_t stream) {
+    if (!p) return UAVSAL_EINVAL;
+    if (!p->exec) return UAVSAL_ESTATE;
+    const hipError_t e = hipGraphLaunch(p->exec, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+extern "C" int uavsal_plan_time(uavsal_plan* p, int first, int last, int iters, uavsal_stream_t stream, float* ms) {
+    if (!p || !ms || iters <= 0) return UAVSAL_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess) return (int)hipGetLastError();
+    if (hipEventCreate(&e1) != hipSuccess) { hipEventDestroy(e0); return (int)hipGetLastError(); }
+    int r = 0;
+    hipEventRecord(e0, s);
+    for (int i = 0; i < iters && !r; ++i) r = uavsal_plan_run(p, first, last, stream);
+    hipEventRecord(e1, s);
+    hipError_t e = hipEventSynchronize(e1);
+    float t = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&t, e0, e1);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    if (r) return r;
+    if (e != hipSuccess) return (int)e;
+    *ms = t / iters;
+    return 0;
+}
+
+extern "C" int uavsal_abi_version(void) { return UAVSAL_ABI_VERSION; }
+
+extern "C" int uavsal_sizeof_desc(int which) {
+    switch (which) {
+        case 0: return (int)sizeof(uavsal_conv_desc);
+        case 1: return (int)sizeof(uavsal_dw_desc);
+        case 2: return (int)sizeof(uavsal_stem_desc);
+        case 3: return (int)sizeof(uavsal_bilinear_desc);
+        case 4: return (int)sizeof(uavsal_tdiff_desc);
+        case 5: return (int)sizeof(uavsal_tsum_desc);
+        case 6: return (int)sizeof(uavsal_layout_desc);
+    }
+    return UAVSAL_EINVAL;
+}
+
+extern "C" const char* uavsal_build_info(void) {
+    return "libuavsal_hip gfx950 abi " "1" " (" __DATE__ " " __TIME__ ")";
+}

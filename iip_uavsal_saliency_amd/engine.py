@@ -1,0 +1,483 @@
+"""Host side of the HIP path: turns a `UAVSal` parameter tree into a native launch plan.
+
+Built once per (device, clip count, sequence length, frame size, precision):
+  1. folds every BatchNorm and packs every conv weight (packing.py), uploads them;
+  2. lays the NHWC fp32 activation buffers out in HBM (concatenations become channel
+     slices of one wider buffer; the two 6x-expanded hidden tensors of an inverted
+     residual block live in two scratch buffers shared by all blocks);
+  3. records every kernel launch of reference `UAVSal.forward` (model.py:341-375) into a
+     `uavsal_plan` (C ABI, include/uavsal_hip.h) that is then replayed natively --
+     as a launch loop or as one captured hipGraph.
+`run()` only stages the caller's tensors and launches the plan on torch's current
+stream.  PyTorch is used for device memory and streams, not for arithmetic.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib as L
+from . import packing as P
+from . import synth
+
+
+def _down(n: int) -> int:
+    return (n - 1) // 2 + 1      # 3x3, stride 2, pad 1
+
+
+class V:
+    """A channel slice [coff, coff+C) of an NHWC buffer `[n*h*w, ld]`."""
+    __slots__ = ("t", "ld", "coff", "n", "h", "w", "c")
+
+    def __init__(self, t, n, h, w, c, ld=None, coff=0):
+        self.t, self.n, self.h, self.w, self.c = t, n, h, w, c
+        self.ld = ld if ld is not None else c
+        self.coff = coff
+
+    @property
+    def ptr(self):
+        return self.t.data_ptr() + 4 * self.coff
+
+    def slice(self, coff, c):
+        return V(self.t, self.n, self.h, self.w, c, self.ld, self.coff + coff)
+
+    def frames(self, first, count):
+        """Images [first, first+count) as a view (pointer offset only)."""
+        v = V(self.t, count, self.h, self.w, self.c, self.ld, self.coff)
+        v.coff = self.coff + first * self.h * self.w * self.ld
+        return v
+
+
+class Engine:
+    def __init__(self, model, device, n_seq, seq_len, H, W, ctx_T, ctx_mode="tile",
+                 precision="f32", taps=False, in_dtype=torch.float32, use_graph=False):
+        if precision not in L.PREC:
+            raise ValueError("precision must be one of %s" % list(L.PREC))
+        self.lib = L.load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("Engine needs a cuda (ROCm) device; there is no CPU fallback")
+        self.model, self.n_seq, self.seq_len = model, n_seq, seq_len
+        self.N = n_seq * seq_len
+        self.H, self.W = H, W
+        self.ctx_T, self.ctx_mode = ctx_T, ctx_mode
+        self.prec_name, self.prec = precision, L.PREC[precision]
+        self.keep_taps = taps
+        self.in_dtype = in_dtype
+        self.use_graph = use_graph
+        if self.N % ctx_T:
+            raise RuntimeError("frame count %d is not a multiple of time_dims %d" % (self.N, ctx_T))
+        self.h = _down(_down(_down(H)))
+        self.w = _down(_down(_down(W)))
+        self._keep: List[torch.Tensor] = []        # weights / buffers kept alive
+        self._wcache: Dict[int, tuple] = {}
+        self.ops_meta: List[dict] = []
+        self.stage_ranges: Dict[str, tuple] = {}
+        self.named: Dict[str, V] = {}
+        self._scratch_need = {"E": 0, "D": 0}
+        self._scratch: Dict[str, torch.Tensor] = {}
+        self.plan = None
+        # pass 1 sizes the shared scratch, pass 2 records the launches
+        self._dry = True
+        self._build()
+        for k, need in self._scratch_need.items():
+            self._scratch[k] = torch.empty(max(need, 4), dtype=torch.float32, device=self.device)
+        self._dry = False
+        self.ops_meta, self.stage_ranges, self.named = [], {}, {}
+        self.plan = C.c_void_p(self.lib.uavsal_plan_create())
+        if not self.plan:
+            raise RuntimeError("uavsal_plan_create failed")
+        self._build()
+        self._graph_ready = False
+
+    def __del__(self):
+        try:
+            if getattr(self, "plan", None):
+                self.lib.uavsal_plan_destroy(self.plan)
+                self.plan = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ memory helpers
+    def _buf(self, name, n, h, w, c) -> V:
+        if self._dry:
+            t = _Fake()
+        else:
+            t = torch.empty(n * h * w * c, dtype=torch.float32, device=self.device)
+            self._keep.append(t)
+        v = V(t, n, h, w, c)
+        if name:
+            self.named[name] = v
+        return v
+
+    def _scr(self, kind, n, h, w, c) -> V:
+        numel = n * h * w * c
+        if self._dry:
+            self._scratch_need[kind] = max(self._scratch_need[kind], numel)
+            return V(_Fake(), n, h, w, c)
+        return V(self._scratch[kind], n, h, w, c)
+
+    def _dev(self, t: torch.Tensor) -> torch.Tensor:
+        d = t.contiguous().to(self.device)
+        self._keep.append(d)
+        return d
+
+    def _affine(self, bn, cout):
+        key = ("bn", id(bn))
+        if key not in self._wcache:
+            s, b = P.fold_bn(bn)
+            n = P.roundup(cout, 32)
+            self._wcache[key] = (self._dev(P.pad_vec(s, n, 1.0)), self._dev(P.pad_vec(b, n, 0.0)))
+        return self._wcache[key]
+
+    def _convw(self, conv, sl=None):
+        key = ("w", id(conv), sl, self.prec_name)
+        if key not in self._wcache:
+            w = conv.weight.detach()
+            if sl is not None:
+                w = w[:, sl[0]:sl[1]]
+            self._wcache[key] = self._dev(P.pack_conv_weight(w, self.prec_name))
+        return self._wcache[key]
+
+    # ------------------------------------------------------------------ op recorders
+    def _meta(self, **kw):
+        self.ops_meta.append(kw)
+
+    def _add(self, fn, desc, what):
+        r = fn(self.plan, C.byref(desc))
+        if r < 0:
+            L.check(r, what)
+
+    def conv(self, name, a: V, conv, bn, out: V, act, taps=1, res: Optional[V] = None, wslice=None,
+             epi=L.EPI_AFFINE, aux: Optional[V] = None, n_img=None, strides=None):
+        cin, cout = a.c, out.c
+        n_img = a.n if n_img is None else n_img
+        hw = a.h * a.w
+        flops = 2.0 * n_img * hw * cin * cout * taps
+        byts = 4.0 * n_img * hw * (cin + cout) + 4.0 * cin * cout * taps
+        self._meta(kind="conv%d" % (3 if taps == 9 else 1), name=name, flops=flops, bytes=byts,
+                   M=n_img * hw, K=cin * taps, Nc=cout)
+        if self._dry:
+            return
+        d = L.ConvDesc()
+        st = strides or {}
+        d.a, d.lda, d.a_img_stride = a.ptr, a.ld, st.get("a", hw)
+        d.w = self._convw(conv, wslice).data_ptr()
+        if bn is not None:
+            s, b = self._affine(bn, cout)
+            d.scale, d.bias = s.data_ptr(), b.data_ptr()
+        else:
+            d.scale, d.bias = None, None
+        d.out, d.ldc, d.o_img_stride = out.ptr, out.ld, st.get("o", hw)
+        if res is not None:
+            d.res, d.ldr, d.r_img_stride = res.ptr, res.ld, st.get("r", hw)
+        else:
+            d.res, d.ldr, d.r_img_stride = None, 0, hw
+        if aux is not None:
+            d.aux, d.ldx, d.x_img_stride = aux.ptr, aux.ld, st.get("x", hw)
+        else:
+            d.aux, d.ldx, d.x_img_stride = None, 0, hw
+        d.n_img, d.H, d.W = n_img, a.h, a.w
+        d.Cin, d.Cout, d.taps = cin, cout, taps
+        d.prec, d.act, d.epi, d.tile = self.prec, act, epi, 0
+        self._add(self.lib.uavsal_plan_add_conv, d, "plan_add_conv(%s)" % name)
+
+    def dw(self, name, a: V, conv, bn, out: V, stride, dilation):
+        c = a.c
+        ho, wo = (a.h - 1) // stride + 1, (a.w - 1) // stride + 1
+        byts = 4.0 * a.n * c * (a.h * a.w + ho * wo) + 4.0 * 9 * c + 4.0 * 2 * c
+        self._meta(kind="dw", name=name, flops=2.0 * 9 * a.n * ho * wo * c, bytes=byts)
+        if self._dry:
+            return
+        key = ("dw", id(conv))
+        if key not in self._wcache:
+            s, b = P.fold_bn(bn)
+            self._wcache[key] = (self._dev(P.pack_dw_weight(conv.weight)), self._dev(s), self._dev(b))
+        w9, s, b = self._wcache[key]
+        d = L.DwDesc()
+        d.inp, d.ldi = a.ptr, a.ld
+        d.w9c, d.scale, d.bias = w9.data_ptr(), s.data_ptr(), b.data_ptr()
+        d.out, d.ldo = out.ptr, out.ld
+        d.n_img, d.H, d.W, d.C = a.n, a.h, a.w, c
+        d.stride, d.dilation, d.act = stride, dilation, L.ACT_RELU6
+        self._add(self.lib.uavsal_plan_add_dw, d, "plan_add_dw(%s)" % name)
+
+    def bilinear(self, name, a: V, out: V, src_mod=None, src_div=1):
+        self._meta(kind="bilinear", name=name, flops=0.0, bytes=4.0 * out.n * out.h * out.w * out.c * 2)
+        if self._dry:
+            return
+        d = L.BilinearDesc()
+        d.inp, d.ldi, d.Hi, d.Wi = a.ptr, a.ld, a.h, a.w
+        d.out, d.ldo, d.Ho, d.Wo = out.ptr, out.ld, out.h, out.w
+        d.n_out, d.C = out.n, a.c
+        d.src_mod, d.src_div = (out.n if src_mod is None else src_mod), src_div
+        self._add(self.lib.uavsal_plan_add_bilinear, d, "plan_add_bilinear(%s)" % name)
+
+    def layout(self, name, src_ptr, dst_ptr, n, c, hw, ld, to_nhwc, cpad=0):
+        self._meta(kind="layout", name=name, flops=0.0, bytes=8.0 * n * c * hw)
+        if self._dry:
+            return
+        d = L.LayoutDesc()
+        d.inp, d.out, d.n_img, d.C, d.HW, d.ld, d.to_nhwc, d.Cpad = src_ptr, dst_ptr, n, c, hw, ld, to_nhwc, cpad
+        self._add(self.lib.uavsal_plan_add_layout, d, "plan_add_layout(%s)" % name)
+
+    def ir_block(self, name, x: V, blk, out: V, final_act=L.ACT_NONE):
+        """pw-expand + BN + ReLU6 -> dw3x3 + BN + ReLU6 -> pw-linear + BN [+ x]
+        (dwBlock, reference model.py:74-103; torchvision InvertedResidual)."""
+        seq = blk.conv
+        stride, dil = blk.stride, getattr(blk, "dilation", 1)
+        if blk.expand_ratio != 1:
+            e = self._scr("E", x.n, x.h, x.w, blk.hidden)
+            self.conv(name + ".pw", x, seq[0][0], seq[0][1], e, L.ACT_RELU6)
+            dwc, dwbn, pl, plbn = seq[1][0], seq[1][1], seq[2], seq[3]
+        else:
+            e = x
+            dwc, dwbn, pl, plbn = seq[0][0], seq[0][1], seq[1], seq[2]
+        ho, wo = (x.h - 1) // stride + 1, (x.w - 1) // stride + 1
+        dd = self._scr("D", x.n, ho, wo, blk.hidden)
+        self.dw(name + ".dw", e, dwc, dwbn, dd, stride, dil)
+        self.conv(name + ".pl", dd, pl, plbn, out, final_act, res=x if blk.use_res_connect else None)
+
+    def _mark(self, stage, start):
+        self.stage_ranges[stage] = (start, len(self.ops_meta))
+
+    # ------------------------------------------------------------------ the forward, recorded
+    def _build(self):
+        m, N, h, w = self.model, self.N, self.h, self.w
+        hw = h * w
+        R6, NONE = L.ACT_RELU6, L.ACT_NONE
+        dev = self.device
+        if not self._dry:
+            # boundary staging (NCHW, as the reference caller hands them over)
+            self.x_in = torch.empty((N, 3, self.H, self.W), dtype=self.in_dtype, device=dev)
+            self.cb0_in = torch.empty((N, 8, h, w), dtype=torch.float32, device=dev)
+            self.cb1_in = torch.empty((N, 20, h, w), dtype=torch.float32, device=dev)
+            self.state_in = torch.zeros((self.n_seq, 256, h, w), dtype=torch.float32, device=dev)
+            self.state_out = torch.empty((self.n_seq, 256, h, w), dtype=torch.float32, device=dev)
+            self.out = torch.empty((N, hw), dtype=torch.float32, device=dev)
+            self.logits = torch.empty((N, hw), dtype=torch.float32, device=dev) if self.keep_taps else None
+        feats = m.sfnet.features.features
+
+        # ---- boundary: state and priors NCHW -> NHWC
+        s0 = len(self.ops_meta)
+        h0 = self._buf("h0", self.n_seq, h, w, 256)
+        g0 = self._buf("gauss_in", N, h, w, 8)
+        o0 = self._buf("ob_in", N, h, w, 20)
+        if self._dry:
+            for nm, c in (("state.in", 256), ("gauss.in", 8), ("ob.in", 20)):
+                self._meta(kind="layout", name=nm, flops=0.0, bytes=8.0 * N * c * hw)
+        else:
+            self.layout("state.in", self.state_in.data_ptr(), h0.ptr, self.n_seq, 256, hw, 256, 1)
+            self.layout("gauss.in", self.cb0_in.data_ptr(), g0.ptr, N, 8, hw, 8, 1)
+            self.layout("ob.in", self.cb1_in.data_ptr(), o0.ptr, N, 20, hw, 20, 1)
+        self._mark("boundary_in", s0)
+
+        # ---- backbone: MobileNetV2 features[0:18] (model_feature.py:62-69)
+        s0 = len(self.ops_meta)
+        H1, W1 = _down(self.H), _down(self.W)
+        x = self._buf("f0", N, H1, W1, 32)
+        self._meta(kind="stem", name="features.0", flops=2.0 * 27 * 32 * N * H1 * W1,
+                   bytes=(4.0 if self.in_dtype == torch.float32 else 1.0) * N * 3 * self.H * self.W + 4.0 * N * H1 * W1 * 32)
+        if not self._dry:
+            conv0, bn0 = feats[0][0], feats[0][1]
+            s, b = P.fold_bn(bn0)
+            ws, ss, bs = self._dev(P.pack_stem_weight(conv0.weight)), self._dev(s), self._dev(b)
+            d = L.StemDesc()
+            if self.in_dtype == torch.uint8:
+                d.inp, d.in_u8 = None, self.x_in.data_ptr()
+            else:
+                d.inp, d.in_u8 = self.x_in.data_ptr(), None
+            d.w, d.scale, d.bias = ws.data_ptr(), ss.data_ptr(), bs.data_ptr()
+            d.out, d.ldo = x.ptr, 32
+            d.n_img, d.H, d.W = N, self.H, self.W
+            for i in range(3):
+                d.mean[i], d.stdv[i] = synth.IMAGENET_MEAN[i], synth.IMAGENET_STD[i]
+            self._add(self.lib.uavsal_plan_add_stem, d, "plan_add_stem")
+        tapsrc = {}
+        for i in range(1, 18):
+            blk = feats[i]
+            ho, wo = (x.h - 1) // blk.stride + 1, (x.w - 1) // blk.stride + 1
+            y = self._buf("f%d" % i, N, ho, wo, blk.cout)
+            self.ir_block("features.%d" % i, x, blk, y)
+            x = y
+            tapsrc[i] = y
+        c3, c4, c5 = tapsrc[6], tapsrc[13], tapsrc[17]
+        self.named.update(c3=c3, c4=c4, c5=c5)
+        self._mark("backbone", s0)
+
+        # ---- SRF-Net head (model.py:139-158)
+        s0 = len(self.ops_meta)
+        sf = m.sfnet
+        aspp = self._buf("aspp", N, c5.h, c5.w, 1024)
+        self.conv("aspp1", c5, sf.lv5_aspp1[0], sf.lv5_aspp1[1], aspp.slice(0, 256), R6)
+        self.ir_block("aspp2", c5, sf.lv5_aspp2, aspp.slice(256, 256))
+        self.ir_block("aspp3", c5, sf.lv5_aspp3, aspp.slice(512, 256))
+        self.ir_block("aspp4", c5, sf.lv5_aspp4, aspp.slice(768, 256))
+        x5 = self._buf("x5", N, c5.h, c5.w, 256)
+        self.conv("conv_lv5", aspp, sf.conv_lv5[0], sf.conv_lv5[1], x5, R6)
+        x4 = self._buf("x4", N, c4.h, c4.w, 128)
+        self.conv("conv_lv4", c4, sf.conv_lv4[0], sf.conv_lv4[1], x4, R6)
+        cat = self._buf("srf_cat", N, h, w, 448)
+        self.bilinear("up_c5", x5, cat.slice(0, 256))
+        self.bilinear("up_c4", x4, cat.slice(256, 128))
+        self.conv("conv_lv3", c3, sf.conv_lv3[0], sf.conv_lv3[1], cat.slice(384, 64), R6)
+        x = self._buf("sfnet", N, h, w, 256)
+        self.conv("conv_last", cat, sf.conv_last[0], sf.conv_last[1], x, R6, taps=9)
+        self._mark("srf_head", s0)
+
+        # ---- ST blocks (model.py:235-249)
+        s0 = len(self.ops_meta)
+        for i, st in enumerate(m.st_layer):
+            sp = self._buf("st%d_sp" % i, N, h, w, 256)
+            self.ir_block("st%d.sp" % i, x, st.stconv_sp.spconv, sp)
+            te = st.stconv_te
+            r = self._buf("st%d_red" % i, N, h, w, 32)
+            self.conv("st%d.reduce" % i, x, te.reduce_conv[0], te.reduce_conv[1], r, R6)
+            dif = self._buf("st%d_dif" % i, N, h, w, 64)
+            self._meta(kind="tdiff", name="st%d.tdiff" % i, flops=0.0, bytes=4.0 * N * hw * 96)
+            if not self._dry:
+                d = L.TdiffDesc()
+                d.inp, d.ldi, d.out, d.ldo = r.ptr, 32, dif.ptr, 64
+                d.n_img, d.HW, d.C, d.seq_len = N, hw, 32, self.seq_len
+                self._add(self.lib.uavsal_plan_add_tdiff, d, "plan_add_tdiff")
+            t1 = self._buf("st%d_te1" % i, N, h, w, 32)
+            self.ir_block("st%d.sub" % i, dif, te.sub_conv, t1)
+            ssum = self._buf("st%d_sum" % i, N, h, w, 256)
+            self.conv("st%d.te_last" % i, t1, te.last_conv[0], te.last_conv[1], ssum, R6, res=sp)   # x_sp + x_te
+            y = self._buf("st%d" % i, N, h, w, 256)
+            self.conv("st%d.last" % i, ssum, st.stconv_last[0], st.stconv_last[1], y, R6, res=x)    # x + out
+            x = y
+        self._mark("st_blocks", s0)
+
+        # ---- fuse + multi-prior net (model.py:344-365)
+        s0 = len(self.ops_meta)
+        fu = self._buf("fu320", N, h, w, 320)
+        xs = fu.slice(0, 256)
+        self.ir_block("fust", x, m.fust_layer[0], xs)
+        cb = self._buf("cb192", N, h, w, 192)
+        g1 = self._buf("gauss1", N, h, w, 64)
+        self.ir_block("gauss.0", g0, m.gauss_cb_layer[0], g1)
+        self.ir_block("gauss.1", g1, m.gauss_cb_layer[1], cb.slice(0, 64))
+        o1 = self._buf("ob1", N, h, w, 64)
+        self.ir_block("ob.0", o0, m.ob_cb_layer[0], o1)
+        self.ir_block("ob.1", o1, m.ob_cb_layer[1], cb.slice(64, 64))
+        B = N // self.ctx_T
+        tsum = self._buf("ctx_sum", B, h, w, 256)
+        self._meta(kind="tsum", name="ctx.sum", flops=0.0, bytes=4.0 * (N + B) * hw * 256)
+        if not self._dry:
+            d = L.TsumDesc()
+            d.inp, d.ldi, d.out, d.ldo = xs.ptr, 320, tsum.ptr, 256
+            d.n_groups, d.T, d.HW, d.C = B, self.ctx_T, hw, 256
+            self._add(self.lib.uavsal_plan_add_tsum, d, "plan_add_tsum")
+        h2, w2 = _down(h), _down(w)
+        cx1 = self._buf("ctx1", B, h2, w2, 64)
+        self.ir_block("ctx.0", tsum, m.cxt_cb_prior[0], cx1)
+        h3, w3 = _down(h2), _down(w2)
+        cx2 = self._buf("ctx2", B, h3, w3, 64)
+        self.ir_block("ctx.1", cx1, m.cxt_cb_prior[1], cx2)
+        if self.ctx_mode == "tile":      # cb_cxt.repeat(T,1,1,1): frame k <- chunk k % B (model.py:361)
+            self.bilinear("ctx.up", cx2, cb.slice(128, 64), src_mod=B, src_div=1)
+        else:                            # independent clips: frame (c,t) <- clip c
+            self.bilinear("ctx.up", cx2, cb.slice(128, 64), src_mod=N, src_div=self.ctx_T)
+        self.ir_block("fucb", cb, m.fucb_layer[0], fu.slice(256, 64))
+        self.named["fust_in_cb"] = fu.slice(256, 64)
+        xf = self._buf("prefuse", N, h, w, 256)
+        self.ir_block("fucbst", fu, m.fucbst_layer[0], xf)
+        self._mark("prior_fuse", s0)
+
+        # ---- ConvTWA recurrence (model_convlstm.py:276-292, 368-371)
+        s0 = len(self.ops_meta)
+        rc = m.rnn.cell_list[0].rnn_conv
+        pre = self._buf("twa_pre", N, h, w, 256)
+        self.conv("twa.wx", xf, rc, None, pre, NONE, taps=9, wslice=(0, 256))        # W[:, :256] * x_t, all t
+        ro = self._buf("rnn", N, h, w, 256)
+        Lq = self.seq_len
+        for t in range(Lq):
+            a = h0 if t == 0 else ro.frames(t - 1, self.n_seq)
+            a = V(a.t, self.n_seq, h, w, 256, 256, a.coff)
+            strides = {"a": hw if t == 0 else Lq * hw, "o": Lq * hw, "r": Lq * hw, "x": Lq * hw}
+            self.conv("twa.step%d" % t, a, rc, None, ro.frames(t, self.n_seq), NONE, taps=9, wslice=(256, 512),
+                      epi=L.EPI_TWA, res=xf.frames(t, self.n_seq), aux=pre.frames(t, self.n_seq),
+                      n_img=self.n_seq, strides=strides)
+        self._mark("twa", s0)
+
+        # ---- decoder + sigmoid (model.py:372-373), state back to NCHW
+        s0 = len(self.ops_meta)
+        outv = V(_Fake() if self._dry else self.out, N, h, w, 1)
+        if self.keep_taps:
+            lv = V(_Fake() if self._dry else self.logits, N, h, w, 1)
+            self.ir_block("conv_out_st.logits", ro, m.conv_out_st, lv, final_act=NONE)
+        self.ir_block("conv_out_st", ro, m.conv_out_st, outv, final_act=L.ACT_SIGMOID)
+        for c in range(self.n_seq):
+            last = ro.frames(c * Lq + Lq - 1, 1)
+            if self._dry:
+                self._meta(kind="layout", name="state.out", flops=0.0, bytes=8.0 * 256 * hw)
+            else:
+                self.layout("state.out", last.ptr, self.state_out.data_ptr() + 4 * c * 256 * hw, 1, 256, hw, 256, 0)
+        self._mark("decoder", s0)
+
+    # ------------------------------------------------------------------ execution
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def launch(self):
+        """Launch the recorded plan once on torch's current stream (no staging, no sync)."""
+        if self.use_graph:
+            if not self._graph_ready:
+                L.check(self.lib.uavsal_plan_run(self.plan, 0, -1, self._stream()), "plan_run (warm-up)")
+                torch.cuda.current_stream(self.device).synchronize()
+                L.check(self.lib.uavsal_plan_graph_build(self.plan, self._stream()), "plan_graph_build")
+                self._graph_ready = True
+            L.check(self.lib.uavsal_plan_graph_launch(self.plan, self._stream()), "plan_graph_launch")
+        else:
+            L.check(self.lib.uavsal_plan_run(self.plan, 0, -1, self._stream()), "plan_run")
+
+    def stage_inputs(self, x, cb0, cb1, state):
+        self.x_in.copy_(x.reshape(self.x_in.shape))
+        self.cb0_in.copy_(cb0.reshape(self.cb0_in.shape))
+        self.cb1_in.copy_(cb1.reshape(self.cb1_in.shape))
+        if state is None:
+            self.state_in.zero_()
+        else:
+            self.state_in.copy_(state.reshape(self.state_in.shape))
+
+    def run(self, x, cb0, cb1, state=None, taps: Optional[dict] = None):
+        if x.dtype != self.in_dtype:
+            raise RuntimeError("engine built for %s frames, got %s" % (self.in_dtype, x.dtype))
+        with torch.cuda.device(self.device):
+            self.stage_inputs(x, cb0, cb1, state)
+            self.launch()
+            out = self.out.clone()
+            st = self.state_out.clone()
+            if taps is not None:
+                if not self.keep_taps:
+                    raise RuntimeError("engine was built without taps")
+                for k in ("c3", "c4", "c5", "sfnet", "st0", "st1", "fust_in_cb", "prefuse", "rnn"):
+                    taps[k] = self.tap(k)
+                taps["logits"] = self.logits.clone().view(self.N, 1, self.h, self.w)
+        return out, st
+
+    def tap(self, name) -> torch.Tensor:
+        """NCHW copy of a named NHWC buffer (debug / parity tests)."""
+        v = self.named[name]
+        t = v.t.view(v.n, v.h, v.w, v.ld) if v.t.numel() == v.n * v.h * v.w * v.ld else None
+        if t is None:
+            raise RuntimeError("tap %s is not a dense buffer" % name)
+        return t[..., v.coff:v.coff + v.c].permute(0, 3, 1, 2).contiguous()
+
+    def time_ops(self, first, last, iters=10) -> float:
+        """Average device milliseconds for ops [first,last) measured with hipEvents on the launch stream."""
+        ms = C.c_float(0.0)
+        L.check(self.lib.uavsal_plan_time(self.plan, first, last, iters, self._stream(), C.byref(ms)), "plan_time")
+        return float(ms.value)
+
+
+class _Fake:
+    """Stand-in tensor for the sizing pass."""
+    def data_ptr(self):
+        return 0
+
+    def numel(self):
+        return 0

@@ -1,0 +1,287 @@
+"""Drop-in `UAVSal(nn.Module)` for the reference's per-frame saliency inference path.
+
+Same constructor, attribute names, `state_dict` keys (685 entries, 13 407 338
+parameters) and `forward(x, cb, in_state) -> (out, x_state)` contract as the
+reference's `model.UAVSal` (reference model.py:254-375), so `Demo_Test.py:33-35,85`
+works unchanged -- but the module tree only *holds parameters*: every
+convolution, BatchNorm, ReLU6, concat, resize, temporal difference, the ConvTWA
+recurrence and the final sigmoid execute as hand-written HIP kernels for gfx950
+through `engine.Engine` (C ABI: include/uavsal_hip.h).  There is no eager /
+CPU fallback: calling `forward` with CPU tensors or without the built library
+raises.
+
+Extension beyond the reference surface: `forward_clips` (batched independent
+clips) and the `precision` attribute selecting how fp32 data is
+fed to the matrix cores ('f32' exact fp32 MFMA, 'bf16x3' split-bf16, 'bf16').
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .model_convlstm import ConvTWA
+from .model_feature import ReMobileNetV2, _no_eager
+
+feature_inplanes = {"mobilenet_v2": [24, 32, 96, 320]}       # reference model.py:32
+
+
+def init_weights(model, funcname="kaiming_normal", **kwargs):
+    """Random init with the reference's rules (model.py:49-60): convs by `funcname`,
+    BatchNorm weight 1 / bias 0."""
+    fn = {"kaiming_normal": nn.init.kaiming_normal_, "kaiming_uniform": nn.init.kaiming_uniform_,
+          "xavier_uniform": nn.init.xavier_uniform_, "xavier_normal": nn.init.xavier_normal_,
+          "normal": nn.init.normal_, "uniform": nn.init.uniform_}[funcname]
+    for m in model.modules():
+        if isinstance(m, nn.Conv2d):
+            fn(m.weight, **kwargs)
+            if m.bias is not None:
+                nn.init.zeros_(m.bias)
+        elif isinstance(m, nn.BatchNorm2d):
+            nn.init.ones_(m.weight)
+            nn.init.zeros_(m.bias)
+
+
+class BasicConv2d(nn.Sequential):
+    """Conv2d(bias=False) + BatchNorm2d + ReLU6 (reference model.py:65-72)."""
+
+    def __init__(self, in_planes, out_planes, kernel_size=3, stride=1, dilation=1, groups=1):
+        padding = dilation * (kernel_size - 1) // 2
+        super().__init__(
+            nn.Conv2d(in_planes, out_planes, kernel_size, stride, padding, dilation=dilation, groups=groups, bias=False),
+            nn.BatchNorm2d(out_planes), nn.ReLU6(inplace=True))
+
+    def forward(self, x):
+        _no_eager("BasicConv2d")
+
+
+class dwBlock(nn.Module):
+    """Inverted residual block (reference model.py:74-103)."""
+
+    def __init__(self, inp, oup, kernel_size=3, stride=1, expand_ratio=6, dilation=1, res_connect=None):
+        super().__init__()
+        assert stride in (1, 2) and kernel_size == 3
+        hidden = int(round(inp * expand_ratio))
+        self.stride, self.dilation, self.expand_ratio = stride, dilation, expand_ratio
+        self.cin, self.cout, self.hidden = inp, oup, hidden
+        self.use_res_connect = stride == 1 and inp == oup
+        if res_connect is not None:
+            self.use_res_connect = bool(res_connect) and self.use_res_connect
+        layers = []
+        if expand_ratio != 1:
+            layers.append(BasicConv2d(inp, hidden, kernel_size=1))
+        layers += [BasicConv2d(hidden, hidden, kernel_size, stride=stride, dilation=dilation, groups=hidden),
+                   nn.Conv2d(hidden, oup, 1, 1, 0, bias=False), nn.BatchNorm2d(oup)]
+        self.conv = nn.Sequential(*layers)
+
+    def forward(self, x):
+        _no_eager("dwBlock")
+
+
+class uavsal_srfnet_aspp(nn.Module):
+    """SRF-Net (reference model.py:110-158)."""
+
+    def __init__(self, cnn_type="mobilenet_v2", planes=(64, 64, 128, 256), last_channel=256):
+        super().__init__()
+        if cnn_type.lower() != "mobilenet_v2":
+            raise NotImplementedError("the HIP path covers the mobilenet_v2 backbone (Demo_Test.py:33)")
+        planes = list(planes)
+        if last_channel == 128:
+            planes = [32, 32, 64, 128]
+        inpl = feature_inplanes["mobilenet_v2"]
+        self.conv_lv3 = BasicConv2d(inpl[1], planes[1], 1)
+        self.conv_lv4 = BasicConv2d(inpl[2], planes[2], 1)
+        self.lv5_aspp1 = BasicConv2d(inpl[3], planes[3], 1)
+        self.lv5_aspp2 = dwBlock(inpl[3], planes[3], 3, dilation=6)
+        self.lv5_aspp3 = dwBlock(inpl[3], planes[3], 3, dilation=12)
+        self.lv5_aspp4 = dwBlock(inpl[3], planes[3], 3, dilation=18)
+        self.conv_lv5 = BasicConv2d(planes[3] * 4, planes[3], 1)
+        self.conv_last = BasicConv2d(planes[1] + planes[2] + planes[3], last_channel, 3)
+        init_weights(self, "kaiming_normal", mode="fan_out")
+        self.features = ReMobileNetV2(name="mobilenet_v2")
+
+    def forward(self, x):
+        _no_eager("uavsal_srfnet_aspp")
+
+
+class spConv(nn.Module):
+    def __init__(self, inplanes, planes=256, kernel_size=3, stride=1, expand_ratio=6, dilation=1, res_connect=False):
+        super().__init__()
+        self.spconv = dwBlock(inplanes, planes, kernel_size, stride, expand_ratio, dilation, res_connect)
+        init_weights(self, "kaiming_normal", mode="fan_out")
+
+    def forward(self, x):
+        _no_eager("spConv")
+
+
+class teConv_sub(nn.Module):
+    def __init__(self, inplanes, planes=256, time_dims=8, reduction=8, res_connect=False):
+        super().__init__()
+        self.time_dims = time_dims
+        self.res_connect = res_connect and inplanes == planes
+        width = planes // reduction
+        self.reduce_conv = BasicConv2d(inplanes, width, 1)
+        self.sub_conv = dwBlock(2 * width, width, 3, res_connect=False)
+        self.last_conv = BasicConv2d(width, planes, 1)
+        init_weights(self, "kaiming_normal", mode="fan_out")
+
+    def forward(self, x):
+        _no_eager("teConv_sub")
+
+
+class STBlock(nn.Module):
+    def __init__(self, inplanes, planes=256, time_dims=8, fu_type="sum", res_connect=True, **kwargs):
+        super().__init__()
+        if fu_type.lower() != "sum":
+            raise NotImplementedError("UAVSal builds STBlock with fu_type='sum' (model.py:274)")
+        self.res_connect = res_connect and inplanes == planes
+        self.time_dims, self.fu_type, self.inplanes, self.planes = time_dims, "sum", inplanes, planes
+        self.stconv_sp = spConv(inplanes, planes, res_connect=False)
+        self.stconv_te = teConv_sub(inplanes, planes, time_dims, res_connect=False, **kwargs)
+        self.stconv_last = BasicConv2d(planes, planes, 1)
+        init_weights(self, "kaiming_normal", mode="fan_out")
+
+    def forward(self, x):
+        _no_eager("STBlock")
+
+
+class UAVSal(nn.Module):
+    """See module docstring.  Constructor arguments as reference model.py:255-261."""
+
+    def __init__(self, cnn_type="mobilenet_v2", time_dims=5, num_stblock=2, bias_type=[1, 1, 1],
+                 iosize=[360, 640, 45, 80], planes=256, pre_model_path="", precision="f32"):
+        super().__init__()
+        if list(bias_type) != [1, 1, 1]:
+            raise NotImplementedError("the HIP path implements bias_type=[1,1,1] (Demo_Test.py:125)")
+        if planes != 256:
+            raise NotImplementedError("planes=256 is the only configuration on the Demo_Test path")
+        self.time_dims = time_dims
+        self.precision = precision
+        self.use_graph = False          # replay the launch plan as one hipGraph
+        self.sfnet = uavsal_srfnet_aspp(cnn_type, last_channel=planes)
+        self.num_stblock = num_stblock
+        self.st_layer = nn.Sequential(*[
+            STBlock(planes, planes, time_dims=time_dims, reduction=planes // 32, res_connect=True)
+            for _ in range(num_stblock)])
+        self.fust_layer = nn.Sequential(dwBlock(planes, planes, kernel_size=3))
+        self.use_gauss_prior, self.use_ob_prior, self.use_context_prior = bias_type
+        self.num_cb = int(np.sum(np.array(bias_type) > 0))
+        self.gauss_cb_layer = nn.Sequential(dwBlock(8, 64, kernel_size=3), dwBlock(64, 64, kernel_size=3))
+        init_weights(self.gauss_cb_layer)
+        self.ob_cb_layer = nn.Sequential(dwBlock(20, 64, kernel_size=3), dwBlock(64, 64, kernel_size=3))
+        init_weights(self.ob_cb_layer)
+        self.cxt_cb_prior = nn.Sequential(dwBlock(planes, 64, kernel_size=3, stride=2),
+                                          dwBlock(64, 64, kernel_size=3, stride=2))
+        init_weights(self.cxt_cb_prior)
+        self.fucb_layer = nn.Sequential(dwBlock(192, planes // 4, kernel_size=3))
+        self.fucbst_layer = nn.Sequential(dwBlock(planes + planes // 4, planes, kernel_size=3))
+        _, _, shape_r_out, shape_c_out = iosize
+        self.rnn = ConvTWA((shape_r_out, shape_c_out), planes, planes, kernel_size=(3, 3), num_layers=1,
+                           batch_first=True, bias=False, return_all_layers=False)
+        self.conv_out_st = dwBlock(planes, 1, kernel_size=3)
+        init_weights(self.st_layer, "kaiming_normal", mode="fan_out")
+        init_weights(self.fust_layer, "kaiming_normal", mode="fan_out")
+        init_weights(self.conv_out_st, "kaiming_normal", mode="fan_out")
+        self._engines: Dict[tuple, "object"] = {}
+        if pre_model_path and os.path.exists(pre_model_path):
+            self.load_state_dict(torch.load(pre_model_path, map_location="cpu").state_dict(), strict=False)
+
+    # -- engines are built from the current parameter values; drop them when those change
+    def _drop_engines(self):
+        self._engines = {}
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self._drop_engines()
+        return out
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self._drop_engines()
+        return out
+
+    def train(self, mode: bool = True):
+        if mode:
+            self._drop_engines()
+        return super().train(mode)
+
+    def _engine(self, device, n_seq, seq_len, H, W, ctx_mode, taps=False, in_dtype=torch.float32):
+        from .engine import Engine
+        key = (str(device), n_seq, seq_len, H, W, self.time_dims if ctx_mode == "tile" else seq_len,
+               ctx_mode, self.precision, bool(taps), in_dtype, bool(self.use_graph))
+        eng = self._engines.get(key)
+        if eng is None:
+            eng = Engine(self, device, n_seq=n_seq, seq_len=seq_len, H=H, W=W,
+                         ctx_T=key[5], ctx_mode=ctx_mode, precision=self.precision, taps=taps,
+                         in_dtype=in_dtype, use_graph=self.use_graph)
+            self._engines[key] = eng
+        return eng
+
+    def _check_common(self, x):
+        if self.training:
+            raise RuntimeError("UAVSal HIP path is inference-only: call model.eval() (Demo_Test.py:55)")
+        if not x.is_cuda:
+            raise RuntimeError("UAVSal.forward needs tensors on the MI355X (cuda) device; "
+                               "there is no CPU fallback in this package")
+        if x.dtype != torch.float32 and x.dtype != torch.uint8:
+            raise RuntimeError("frames must be float32 (ImageNet-normalised) or uint8 RGB")
+
+    @torch.no_grad()
+    def forward(self, x, cb, in_state=None, taps: Optional[dict] = None):
+        """x `[B*T,3,H,W]` float32 NCHW (ImageNet-normalised RGB; uint8 RGB is also accepted and
+        normalised on load), cb = [gauss `[B*T,8,h,w]`, ob `[B*T,20,h,w]`], in_state = None or
+        [`[1,256,h,w]`]  ->  (out `[B*T,1,h,w]`, [h_last `[1,256,h,w]`]); reference model.py:341-375.
+        The frames of one call form ONE sequence for the temporal differences and the recurrence;
+        the context prior is summed per chunk of `time_dims` frames and tiled (model.py:357-361)."""
+        self._check_common(x)
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise RuntimeError("x must be [B*T, 3, H, W]")
+        n, _, H, W = x.shape
+        if n < 2:
+            raise RuntimeError("UAVSal.forward needs at least 2 frames per call (reference teConv_sub, model.py:194)")
+        if n % self.time_dims:
+            raise RuntimeError("shape '[%d, %d, ...]' is invalid for input of %d frames (model.py:357)" % (
+                n // self.time_dims, self.time_dims, n))
+        eng = self._engine(x.device, 1, n, H, W, "tile", taps is not None, x.dtype)
+        h, w = eng.h, eng.w
+        self._check_cb(cb, n, h, w)
+        st = None
+        if in_state is not None:
+            st = in_state[0]
+            if tuple(st.shape) != (1, 256, h, w):
+                raise RuntimeError("in_state[0] must be [1, 256, %d, %d]" % (h, w))
+        out, state = eng.run(x, cb[0], cb[1], st, taps)
+        return out.view(n, 1, h, w), [state.view(1, 256, h, w)]
+
+    @torch.no_grad()
+    def forward_clips(self, x, cb, states=None, taps: Optional[dict] = None):
+        """Batched independent clips: x `[C,T,3,H,W]`, cb = [`[C,T,8,h,w]`,
+        `[C,T,20,h,w]`], states `[C,256,h,w]` or None -> (out `[C,T,1,h,w]`, states `[C,256,h,w]`),
+        equal to C reference calls with time_dims=T and a zero (or the given) state each."""
+        self._check_common(x)
+        if x.dim() != 5 or x.shape[2] != 3:
+            raise RuntimeError("x must be [C, T, 3, H, W]")
+        C, T, _, H, W = x.shape
+        if T < 2:
+            raise RuntimeError("each clip needs at least 2 frames (reference teConv_sub, model.py:194)")
+        eng = self._engine(x.device, C, T, H, W, "clip", taps is not None, x.dtype)
+        h, w = eng.h, eng.w
+        self._check_cb([cb[0].reshape(C * T, *cb[0].shape[2:]), cb[1].reshape(C * T, *cb[1].shape[2:])], C * T, h, w)
+        if states is not None and tuple(states.shape) != (C, 256, h, w):
+            raise RuntimeError("states must be [C, 256, h, w]")
+        out, state = eng.run(x.reshape(C * T, 3, H, W), cb[0].reshape(C * T, 8, h, w),
+                             cb[1].reshape(C * T, 20, h, w), states, taps)
+        return out.view(C, T, 1, h, w), state.view(C, 256, h, w)
+
+    @staticmethod
+    def _check_cb(cb, n, h, w):
+        if len(cb) != 2:
+            raise RuntimeError("cb must be [gauss priors, observed priors] (Demo_Test.py:14-27)")
+        if tuple(cb[0].shape) != (n, 8, h, w) or tuple(cb[1].shape) != (n, 20, h, w):
+            raise RuntimeError("cb shapes must be [%d,8,%d,%d] and [%d,20,%d,%d], got %s and %s" % (
+                n, h, w, n, h, w, tuple(cb[0].shape), tuple(cb[1].shape)))
+        if cb[0].dtype != torch.float32 or cb[1].dtype != torch.float32:
+            raise RuntimeError("cb tensors must be float32")

@@ -1,0 +1,177 @@
+"""Single-operator wrappers over the C ABI (one launch each, outputs allocated through
+torch, launched on torch's current stream).  Used by the per-kernel parity tests and
+handy for experiments; the model path records plans instead (engine.py).
+All activations are NHWC fp32 cuda tensors `[n, h, w, c]` (channel slices allowed:
+pass a narrowed view `t[..., a:b]`)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+from . import packing as P
+
+
+def _stream(t):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _nhwc_view(t: torch.Tensor):
+    """(ptr, ld, n, h, w, c) of an NHWC tensor or of a channel slice of one."""
+    if t.dim() != 4 or t.dtype != torch.float32 or not t.is_cuda:
+        raise RuntimeError("expected a float32 cuda NHWC tensor [n,h,w,c]")
+    n, h, w, c = t.shape
+    ld = t.stride(2)
+    if t.stride(3) != 1 or t.stride(1) != w * ld or t.stride(0) != h * w * ld:
+        raise RuntimeError("tensor is not an NHWC buffer (or channel slice of one)")
+    return t.data_ptr(), ld, n, h, w, c
+
+
+def conv_gemm(x, weight, scale=None, bias=None, act=L.ACT_NONE, res=None, out=None, prec="f32", tile=0):
+    """Dense 1x1 / 3x3 conv (+ folded BN, activation, residual).  `weight` [Cout,Cin,k,k] (cpu or cuda)."""
+    lib = L.load()
+    ap, lda, n, h, w, cin = _nhwc_view(x)
+    cout, taps = weight.shape[0], weight.shape[2] * weight.shape[3]
+    if out is None:
+        out = torch.empty((n, h, w, cout), dtype=torch.float32, device=x.device)
+    op, ldc, *_ = _nhwc_view(out)
+    wp = P.pack_conv_weight(weight, prec).to(x.device)
+    keep = [wp]
+    d = L.ConvDesc()
+    d.a, d.lda, d.a_img_stride = ap, lda, h * w
+    d.w = wp.data_ptr()
+    if scale is not None:
+        npad = P.roundup(cout, 32)
+        s = P.pad_vec(scale, npad, 1.0).to(x.device)
+        b = P.pad_vec(bias, npad, 0.0).to(x.device)
+        keep += [s, b]
+        d.scale, d.bias = s.data_ptr(), b.data_ptr()
+    d.out, d.ldc, d.o_img_stride = op, ldc, h * w
+    if res is not None:
+        rp, ldr, *_ = _nhwc_view(res)
+        d.res, d.ldr, d.r_img_stride = rp, ldr, h * w
+    d.n_img, d.H, d.W, d.Cin, d.Cout, d.taps = n, h, w, cin, cout, taps
+    d.prec, d.act, d.epi, d.tile = L.PREC[prec], act, L.EPI_AFFINE, tile
+    L.check(lib.uavsal_conv_gemm(C.byref(d), _stream(x)), "uavsal_conv_gemm")
+    torch.cuda.current_stream(x.device).synchronize()   # `keep` must outlive the launch
+    return out
+
+
+def twa_step(x_t, h_prev, pre_t, w_h, prec="f32", tile=0):
+    """One ConvTWA step given pre_t = conv3x3(W[:, :C], x_t): returns h_t (NHWC)."""
+    lib = L.load()
+    ap, lda, n, h, w, c = _nhwc_view(h_prev)
+    xp, ldr, *_ = _nhwc_view(x_t)
+    pp, ldx, *_ = _nhwc_view(pre_t)
+    out = torch.empty((n, h, w, c), dtype=torch.float32, device=x_t.device)
+    wp = P.pack_conv_weight(w_h, prec).to(x_t.device)
+    d = L.ConvDesc()
+    d.a, d.lda, d.a_img_stride = ap, lda, h * w
+    d.w = wp.data_ptr()
+    d.out, d.ldc, d.o_img_stride = out.data_ptr(), c, h * w
+    d.res, d.ldr, d.r_img_stride = xp, ldr, h * w
+    d.aux, d.ldx, d.x_img_stride = pp, ldx, h * w
+    d.n_img, d.H, d.W, d.Cin, d.Cout, d.taps = n, h, w, c, c, 9
+    d.prec, d.act, d.epi, d.tile = L.PREC[prec], L.ACT_NONE, L.EPI_TWA, tile
+    L.check(lib.uavsal_conv_gemm(C.byref(d), _stream(x_t)), "uavsal_conv_gemm(TWA)")
+    torch.cuda.current_stream(x_t.device).synchronize()
+    return out
+
+
+def dw3x3(x, weight, scale, bias, stride=1, dilation=1, act=L.ACT_RELU6, out=None):
+    lib = L.load()
+    ip, ldi, n, h, w, c = _nhwc_view(x)
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    if out is None:
+        out = torch.empty((n, ho, wo, c), dtype=torch.float32, device=x.device)
+    op, ldo, *_ = _nhwc_view(out)
+    w9 = P.pack_dw_weight(weight).to(x.device)
+    s, b = scale.float().contiguous().to(x.device), bias.float().contiguous().to(x.device)
+    d = L.DwDesc()
+    d.inp, d.ldi, d.w9c, d.scale, d.bias = ip, ldi, w9.data_ptr(), s.data_ptr(), b.data_ptr()
+    d.out, d.ldo = op, ldo
+    d.n_img, d.H, d.W, d.C, d.stride, d.dilation, d.act = n, h, w, c, stride, dilation, act
+    L.check(lib.uavsal_dw3x3(C.byref(d), _stream(x)), "uavsal_dw3x3")
+    torch.cuda.current_stream(x.device).synchronize()
+    return out
+
+
+def stem_conv(x_nchw, weight, scale, bias):
+    lib = L.load()
+    n, _, H, W = x_nchw.shape
+    ho, wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    out = torch.empty((n, ho, wo, 32), dtype=torch.float32, device=x_nchw.device)
+    ws = P.pack_stem_weight(weight).to(x_nchw.device)
+    s, b = scale.float().contiguous().to(x_nchw.device), bias.float().contiguous().to(x_nchw.device)
+    x_nchw = x_nchw.contiguous()
+    d = L.StemDesc()
+    if x_nchw.dtype == torch.uint8:
+        d.inp, d.in_u8 = None, x_nchw.data_ptr()
+    else:
+        d.inp, d.in_u8 = x_nchw.data_ptr(), None
+    d.w, d.scale, d.bias, d.out, d.ldo = ws.data_ptr(), s.data_ptr(), b.data_ptr(), out.data_ptr(), 32
+    d.n_img, d.H, d.W = n, H, W
+    from .synth import IMAGENET_MEAN, IMAGENET_STD
+    for i in range(3):
+        d.mean[i], d.stdv[i] = IMAGENET_MEAN[i], IMAGENET_STD[i]
+    L.check(lib.uavsal_stem_conv(C.byref(d), _stream(out)), "uavsal_stem_conv")
+    torch.cuda.current_stream(out.device).synchronize()
+    return out
+
+
+def bilinear_ac(x, ho, wo, out=None, n_out=None, src_mod=None, src_div=1):
+    lib = L.load()
+    ip, ldi, n, h, w, c = _nhwc_view(x)
+    n_out = n if n_out is None else n_out
+    if out is None:
+        out = torch.empty((n_out, ho, wo, c), dtype=torch.float32, device=x.device)
+    op, ldo, *_ = _nhwc_view(out)
+    d = L.BilinearDesc()
+    d.inp, d.ldi, d.Hi, d.Wi, d.out, d.ldo, d.Ho, d.Wo = ip, ldi, h, w, op, ldo, ho, wo
+    d.n_out, d.C, d.src_mod, d.src_div = n_out, c, (n_out if src_mod is None else src_mod), src_div
+    L.check(lib.uavsal_bilinear_ac(C.byref(d), _stream(x)), "uavsal_bilinear_ac")
+    return out
+
+
+def tdiff(x, seq_len):
+    lib = L.load()
+    ip, ldi, n, h, w, c = _nhwc_view(x)
+    out = torch.empty((n, h, w, 2 * c), dtype=torch.float32, device=x.device)
+    d = L.TdiffDesc()
+    d.inp, d.ldi, d.out, d.ldo, d.n_img, d.HW, d.C, d.seq_len = ip, ldi, out.data_ptr(), 2 * c, n, h * w, c, seq_len
+    L.check(lib.uavsal_tdiff(C.byref(d), _stream(x)), "uavsal_tdiff")
+    return out
+
+
+def tsum(x, T):
+    lib = L.load()
+    ip, ldi, n, h, w, c = _nhwc_view(x)
+    out = torch.empty((n // T, h, w, c), dtype=torch.float32, device=x.device)
+    d = L.TsumDesc()
+    d.inp, d.ldi, d.out, d.ldo, d.n_groups, d.T, d.HW, d.C = ip, ldi, out.data_ptr(), c, n // T, T, h * w, c
+    L.check(lib.uavsal_tsum(C.byref(d), _stream(x)), "uavsal_tsum")
+    return out
+
+
+def to_nhwc(x_nchw, cpad=0):
+    lib = L.load()
+    x_nchw = x_nchw.contiguous()
+    n, c, h, w = x_nchw.shape
+    ld = max(c, cpad)
+    out = torch.empty((n, h, w, ld), dtype=torch.float32, device=x_nchw.device)
+    d = L.LayoutDesc()
+    d.inp, d.out, d.n_img, d.C, d.HW, d.ld, d.to_nhwc, d.Cpad = x_nchw.data_ptr(), out.data_ptr(), n, c, h * w, ld, 1, cpad
+    L.check(lib.uavsal_layout(C.byref(d), _stream(out)), "uavsal_layout")
+    return out
+
+
+def to_nchw(x_nhwc):
+    lib = L.load()
+    ip, ld, n, h, w, c = _nhwc_view(x_nhwc)
+    out = torch.empty((n, c, h, w), dtype=torch.float32, device=x_nhwc.device)
+    d = L.LayoutDesc()
+    d.inp, d.out, d.n_img, d.C, d.HW, d.ld, d.to_nhwc, d.Cpad = ip, out.data_ptr(), n, c, h * w, ld, 0, 0
+    L.check(lib.uavsal_layout(C.byref(d), _stream(out)), "uavsal_layout")
+    return out

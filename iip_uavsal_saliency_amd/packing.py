@@ -1,0 +1,70 @@
+"""Host-side weight preparation for the HIP kernels: BatchNorm folding and the packed
+weight layouts documented in include/uavsal_hip.h.  Pure tensor reshuffling on the
+host, done once per engine build (never in the timed path)."""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+BN_EPS = 1e-5  # nn.BatchNorm2d default; the reference never overrides it (model.py:70,95)
+
+# order of the 32 k's of one K tile in the bf16 layouts: chunk c = {4c..4c+3, 16+4c..16+4c+3}
+_K_PERM32 = [k for c in range(4) for k in (list(range(4 * c, 4 * c + 4)) + list(range(16 + 4 * c, 16 + 4 * c + 4)))]
+
+
+def fold_bn(bn: torch.nn.BatchNorm2d) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Eval-mode BatchNorm as y = x*scale + bias (fp64 fold, fp32 result)."""
+    g = bn.weight.detach().double().cpu()
+    b = bn.bias.detach().double().cpu()
+    m = bn.running_mean.detach().double().cpu()
+    v = bn.running_var.detach().double().cpu()
+    scale = g / torch.sqrt(v + bn.eps)
+    bias = b - m * scale
+    return scale.float(), bias.float()
+
+
+def pad_vec(v: torch.Tensor, n: int, fill: float = 0.0) -> torch.Tensor:
+    out = torch.full((n,), fill, dtype=torch.float32)
+    out[: v.numel()] = v.float().cpu()
+    return out
+
+
+def roundup(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def pack_conv_weight(w: torch.Tensor, prec: str) -> torch.Tensor:
+    """`w` [Cout, Cin, kh, kw] (kh=kw in {1,3}) -> packed byte tensor (uint8, 1-D) in the layout
+    `uavsal_conv_gemm` expects for `prec` in {'f32','bf16','bf16x3'}."""
+    w = w.detach().float().cpu()
+    cout, cin, kh, kw = w.shape
+    taps = kh * kw
+    assert taps in (1, 9) and kh == kw
+    kt = 16 if prec == "f32" else 32
+    if taps == 9 and cin % 32:
+        raise RuntimeError("3x3 dense conv needs Cin % 32 == 0")
+    k = taps * cin
+    kpad, npad = roundup(k, kt), roundup(cout, 32)
+    m = torch.zeros(npad, kpad, dtype=torch.float32)
+    m[:cout, :k] = w.permute(0, 2, 3, 1).reshape(cout, k)        # k = tap*Cin + ci
+    if prec == "f32":
+        return m.contiguous().view(torch.uint8).reshape(-1)
+    idx = torch.tensor(_K_PERM32, dtype=torch.long)
+    m = m.view(npad, kpad // 32, 32)[:, :, idx].reshape(npad, kpad)
+    hi = m.to(torch.bfloat16)
+    if prec == "bf16":
+        return hi.contiguous().view(torch.uint8).reshape(-1)
+    lo = (m - hi.float()).to(torch.bfloat16)
+    return torch.stack([hi, lo], 0).contiguous().view(torch.uint8).reshape(-1)
+
+
+def pack_dw_weight(w: torch.Tensor) -> torch.Tensor:
+    """depthwise `w` [C, 1, 3, 3] -> tap-major [9, C] fp32."""
+    c = w.shape[0]
+    return w.detach().float().cpu().reshape(c, 9).t().contiguous()
+
+
+def pack_stem_weight(w: torch.Tensor) -> torch.Tensor:
+    """stem `w` [32, 3, 3, 3] -> [27, 32] fp32, row = ci*9 + ky*3 + kx."""
+    return w.detach().float().cpu().reshape(32, 27).t().contiguous()

@@ -1,0 +1,224 @@
+/*
+ * uavsal_hip.h -- C ABI of libuavsal_hip.so, the MI355X (gfx950) kernels behind
+ * UAVSal.forward.
+ *
+ * The reference (zhangkao/IIP_UAVSal_Saliency) is pure Python: it has no native
+ * boundary of its own.  Every arithmetic step of `UAVSal.forward`
+ * (model.py:341-375) is a stock torch.nn operator.  This header therefore
+ * defines the native boundary the drop-in needs: one entry point per operator
+ * class of the hot path, each citing the reference expression (file:line,
+ * relative to the reference root) it replaces.  Plain pointers and sizes only:
+ * no torch types, no allocation, no ownership transfer, no global state.
+ *
+ * Conventions
+ *   - all tensors are fp32 device pointers, activations NHWC
+ *     ([image][y][x][channel]); `ld*` is the channel stride of the buffer in
+ *     floats, so a pointer + ld pair can address a channel slice of a wider
+ *     buffer (this is how torch.cat, model.py:146,155,363,365, disappears);
+ *   - `*_img_stride` is the distance between consecutive images in PIXELS
+ *     (H*W for a dense batch; T*H*W when one time step of C clips is addressed,
+ *     model_convlstm.py:368-371);
+ *   - channel counts, ld's and slice offsets are multiples of 4 floats (16 B);
+ *   - `stream` is a hipStream_t passed as void*; kernels are launched on it and
+ *     nothing synchronises;
+ *   - every function returns 0 on success, a positive hipError_t if the launch
+ *     failed, or a negative UAVSAL_E* code if the arguments were rejected.
+ *
+ * Built for gfx950 only.  No CUDA path, no CPU fallback.
+ */
+#ifndef UAVSAL_HIP_H
+#define UAVSAL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UAVSAL_ABI_VERSION 1
+
+/* argument errors */
+#define UAVSAL_EINVAL   (-1)  /* null pointer / non-positive size */
+#define UAVSAL_EALIGN   (-2)  /* channel count / ld / pointer not 16-byte aligned */
+#define UAVSAL_ESHAPE   (-3)  /* shape not supported by the kernel (see entry point) */
+#define UAVSAL_ESTATE   (-4)  /* plan used in the wrong state */
+
+/* GEMM operand precision (how fp32 activations/weights are fed to the matrix cores) */
+#define UAVSAL_PREC_F32     0 /* v_mfma_f32_32x32x2_f32: exact fp32 fma chain */
+#define UAVSAL_PREC_BF16X3  1 /* 3x v_mfma_f32_32x32x16_bf16 on a hi/lo bf16 split, fp32 accumulate */
+#define UAVSAL_PREC_BF16    2 /* 1x bf16 MFMA, fp32 accumulate */
+
+#define UAVSAL_ACT_NONE     0
+#define UAVSAL_ACT_RELU6    1 /* nn.ReLU6, model.py:71 */
+#define UAVSAL_ACT_SIGMOID  2 /* torch.sigmoid, model.py:373 */
+
+#define UAVSAL_EPI_AFFINE   0 /* y = act(acc*scale + bias) [+ res] */
+#define UAVSAL_EPI_TWA      1 /* ConvTWA gate + state update, see uavsal_conv_desc */
+
+typedef void* uavsal_stream_t;
+
+/*
+ * Dense 1x1 or 3x3 (stride 1, pad 1) convolution as an implicit GEMM on the
+ * matrix cores, with the folded BatchNorm, activation, residual add and the
+ * ConvTWA state update fused into the epilogue.
+ *
+ * Replaces: BasicConv2d k=1 / k=3 (model.py:65-72: Conv2d(bias=False) + BatchNorm2d
+ * (eval: scale = gamma/sqrt(var+1e-5), bias = beta - mean*scale) + ReLU6); the
+ * pw-linear Conv2d+BatchNorm2d tail of dwBlock (model.py:94-95) with its residual
+ * (model.py:100-101); torchvision InvertedResidual's pointwise convs; STBlock's
+ * `x_sp + x_te` and `x + out` adds (model.py:241,247) as post-activation residuals;
+ * the final torch.sigmoid (model.py:373); and, with epi=UAVSAL_EPI_TWA,
+ * ConvTWACell.forward (model_convlstm.py:276-292).
+ *
+ * EPI_AFFINE: out[m, n] = act(acc[m, n] * scale[n] + bias[n]) + (res ? res[m, n] : 0)
+ *             (scale == NULL -> raw accumulator, bias ignored)
+ * EPI_TWA:    a = h_{t-1} (Cin == Cout), w = the W[:, Cin:, :, :] half of rnn_conv,
+ *             aux = conv3x3(W[:, :Cin], x_t) precomputed for this step, res = x_t:
+ *             i = sigmoid(acc + aux);  out = i * res + (1 - i) * a
+ *
+ * Weights `w` are pre-packed by the host (iip_uavsal_saliency_amd/packing.py):
+ *   k index = tap * Cin + ci, rows padded to Npad = roundup(Cout, 32), K padded to
+ *   Kpad = roundup(taps * Cin, KT) with zeros, KT = 16 (F32) or 32 (BF16*);
+ *   F32:    float  [Npad][Kpad]
+ *   BF16:   uint16 [Npad][Kpad]            (bf16 bits, round-to-nearest-even)
+ *   BF16X3: uint16 hi[Npad][Kpad] then uint16 lo[Npad][Kpad], lo = bf16(w - hi)
+ *   in the BF16* layouts each group of 32 k's is stored in the order
+ *   {0-3,16-19, 4-7,20-23, 8-11,24-27, 12-15,28-31} (matches the A staging).
+ * taps == 9 requires Cin % 32 == 0.
+ */
+typedef struct uavsal_conv_desc {
+    const float* a;      int32_t lda;  int64_t a_img_stride;
+    const void*  w;
+    const float* scale;  const float* bias;          /* [>= Cout] each, or NULL */
+    float*       out;    int32_t ldc;  int64_t o_img_stride;
+    const float* res;    int32_t ldr;  int64_t r_img_stride;   /* NULL = none */
+    const float* aux;    int32_t ldx;  int64_t x_img_stride;   /* EPI_TWA only */
+    int32_t n_img, H, W;         /* output == input spatial size */
+    int32_t Cin, Cout, taps;     /* taps: 1 or 9 */
+    int32_t prec, act, epi;
+    int32_t tile;                /* 0 = auto; else 1: 128x128, 2: 128x64, 3: 128x32, 4: 64x64 block tile */
+} uavsal_conv_desc;
+
+int uavsal_conv_gemm(const uavsal_conv_desc* d, uavsal_stream_t stream);
+
+/*
+ * Depthwise 3x3 convolution + folded BatchNorm + ReLU6, NHWC, stride 1 or 2,
+ * dilation d (padding = d), one launch for the whole batch.
+ * Replaces: the `groups=hidden_dim` BasicConv2d of dwBlock (model.py:92) and
+ * torchvision InvertedResidual's depthwise ConvBNReLU.
+ * w9c is tap-major: w9c[(ky*3+kx)*C + c] = weight[c, 0, ky, kx].
+ * Ho = (H - 1) / stride + 1, Wo likewise (pad = dilation, kernel 3).
+ * stride 2 requires dilation 1.
+ */
+typedef struct uavsal_dw_desc {
+    const float* in;   int32_t ldi;
+    const float* w9c;  const float* scale;  const float* bias;
+    float*       out;  int32_t ldo;
+    int32_t n_img, H, W, C, stride, dilation, act;
+} uavsal_dw_desc;
+
+int uavsal_dw3x3(const uavsal_dw_desc* d, uavsal_stream_t stream);
+
+/*
+ * Stem: dense 3x3 stride-2 pad-1 convolution 3 -> 32 + BatchNorm + ReLU6 reading the
+ * caller's NCHW fp32 frames and writing NHWC.  Replaces torchvision
+ * mobilenet_v2().features[0] as run by ReMobileNetV2.forward (model_feature.py:63).
+ * w is [27][32]: w[(ci*9 + ky*3 + kx)*32 + co] = weight[co, ci, ky, kx].
+ * If `in_u8` is non-NULL it is used instead of `in`: uint8 RGB frames [n,3,H,W] that are
+ * normalised on load, (v/255 - mean[c]) / stdv[c]  (utils_data.py:43-65 normalize_data).
+ */
+typedef struct uavsal_stem_desc {
+    const float*   in;     /* [n_img, 3, H, W] fp32 NCHW, or NULL */
+    const uint8_t* in_u8;  /* [n_img, 3, H, W] uint8, or NULL */
+    const float* w;  const float* scale;  const float* bias;
+    float* out;  int32_t ldo;            /* [n_img, Ho, Wo, 32] */
+    int32_t n_img, H, W;
+    float mean[3], stdv[3];
+} uavsal_stem_desc;
+
+int uavsal_stem_conv(const uavsal_stem_desc* d, uavsal_stream_t stream);
+
+/*
+ * Bilinear resize, align_corners=True, NHWC, writing into a channel slice.
+ * Replaces F.interpolate(..., mode='bilinear', align_corners=True) at model.py:152-153
+ * and :360, and -- through the source-image map -- `cb_cxt.repeat(time_dims,1,1,1)`
+ * (model.py:361):  source image of output image n is (n % src_mod) / src_div.
+ *   reference semantics (tiling quirk): src_mod = B, src_div = 1
+ *   batched clips:                      src_mod = n_out, src_div = T
+ *   plain resize:                       src_mod = n_out, src_div = 1
+ */
+typedef struct uavsal_bilinear_desc {
+    const float* in;  int32_t ldi;  int32_t Hi, Wi;
+    float* out;       int32_t ldo;  int32_t Ho, Wo;
+    int32_t n_out, C, src_mod, src_div;
+} uavsal_bilinear_desc;
+
+int uavsal_bilinear_ac(const uavsal_bilinear_desc* d, uavsal_stream_t stream);
+
+/*
+ * Temporal neighbour differences of teConv_sub (model.py:194-200), per sequence of
+ * `seq_len` consecutive images: out[:, 0:C] = x[t]-x[t-1] (t=0: x[1]-x[0]);
+ * out[:, C:2C] = x[t]-x[t+1] (t=last: x[last-1]-x[last]).  seq_len >= 2.
+ */
+typedef struct uavsal_tdiff_desc {
+    const float* in;  int32_t ldi;
+    float* out;       int32_t ldo;
+    int32_t n_img, HW, C, seq_len;
+} uavsal_tdiff_desc;
+
+int uavsal_tdiff(const uavsal_tdiff_desc* d, uavsal_stream_t stream);
+
+/* Sum over groups of T consecutive images (model.py:357-358): out[b] = sum_t in[b*T+t]. */
+typedef struct uavsal_tsum_desc {
+    const float* in;  int32_t ldi;
+    float* out;       int32_t ldo;
+    int32_t n_groups, T, HW, C;
+} uavsal_tsum_desc;
+
+int uavsal_tsum(const uavsal_tsum_desc* d, uavsal_stream_t stream);
+
+/*
+ * Layout change between the caller's NCHW tensors (priors cb[0], cb[1], recurrent
+ * state; Demo_Test.py:14-27,85-86) and the NHWC working buffers.
+ * to_nhwc != 0: nchw -> nhwc (channels C..Cpad-1 of the destination are zero-filled),
+ * else nhwc -> nchw.  `ld` is the NHWC channel stride.
+ */
+typedef struct uavsal_layout_desc {
+    const float* in;  float* out;
+    int32_t n_img, C, HW, ld, to_nhwc, Cpad;
+} uavsal_layout_desc;
+
+int uavsal_layout(const uavsal_layout_desc* d, uavsal_stream_t stream);
+
+/* ---- launch plan: a recorded sequence of the calls above, run natively ------------ */
+typedef struct uavsal_plan uavsal_plan;
+
+uavsal_plan* uavsal_plan_create(void);
+void uavsal_plan_destroy(uavsal_plan* p);
+int uavsal_plan_add_conv(uavsal_plan* p, const uavsal_conv_desc* d);
+int uavsal_plan_add_dw(uavsal_plan* p, const uavsal_dw_desc* d);
+int uavsal_plan_add_stem(uavsal_plan* p, const uavsal_stem_desc* d);
+int uavsal_plan_add_bilinear(uavsal_plan* p, const uavsal_bilinear_desc* d);
+int uavsal_plan_add_tdiff(uavsal_plan* p, const uavsal_tdiff_desc* d);
+int uavsal_plan_add_tsum(uavsal_plan* p, const uavsal_tsum_desc* d);
+int uavsal_plan_add_layout(uavsal_plan* p, const uavsal_layout_desc* d);
+int uavsal_plan_size(const uavsal_plan* p);
+/* launch ops [first, last) in order on `stream` (last < 0: to the end) */
+int uavsal_plan_run(uavsal_plan* p, int first, int last, uavsal_stream_t stream);
+/* capture the whole plan into a hipGraph once, then replay it */
+int uavsal_plan_graph_build(uavsal_plan* p, uavsal_stream_t stream);
+int uavsal_plan_graph_launch(uavsal_plan* p, uavsal_stream_t stream);
+
+/* ---- device timing on the launch stream (hipEvent) and introspection --------------- */
+/* run ops [first,last) `iters` times on `stream`, return average ms per iteration in *ms
+ * (hipEventRecord on `stream` around the loop, hipEventSynchronize on the stop event). */
+int uavsal_plan_time(uavsal_plan* p, int first, int last, int iters, uavsal_stream_t stream, float* ms);
+
+int uavsal_abi_version(void);
+int uavsal_sizeof_desc(int which); /* 0 conv,1 dw,2 stem,3 bilinear,4 tdiff,5 tsum,6 layout */
+const char* uavsal_build_info(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UAVSAL_HIP_H */

@@ -1,0 +1,159 @@
+"""End-to-end parity of the HIP path on the MI355X, through the drop-in `UAVSal` surface.
+
+Checked against (a) the oracle (oracle/uavsal_ref.py, torch-CPU fp32 restatement) on the same
+seeded inputs and (b) the committed golden vectors that oracle/make_goldens.py produced by
+running the reference's own model.py.  Tolerance on the fp32 saliency map: 1e-3 max-abs
+(BASELINE.json north_star); the exact-fp32 MFMA mode is held to 1e-4.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from iip_uavsal_saliency_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+MAP_TOL = {"f32": 1e-4, "bf16x3": 1e-3}
+LOGIT_TOL = {"f32": 1e-3, "bf16x3": 8e-3}     # logits span about +-12
+STATE_TOL = {"f32": 2e-4, "bf16x3": 2e-3}
+
+
+def make_inputs(n, H, W, seed=0, t0=0):
+    h, w = H // 8, W // 8
+    x = torch.from_numpy(synth.normalize_frames(synth.synth_frames_u8(n, H, W, seed, t0)))
+    cb = [torch.from_numpy(synth.gauss_priors(n, h, w)), torch.from_numpy(synth.ob_priors(n, h, w, seed=seed))]
+    return x, cb
+
+
+@pytest.fixture(scope="module")
+def hip_model():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from iip_uavsal_saliency_amd import UAVSal
+    m = UAVSal(time_dims=4)
+    synth.load_synth_weights(m, 0)
+    return m.cuda().eval()
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle.uavsal_ref import build_oracle
+    return build_oracle(time_dims=4, seed=0)
+
+
+def _run_hip(model, T, prec, x, cb, state=None, taps=None):
+    model.time_dims = T
+    model.precision = prec
+    st = None if state is None else [state.cuda()]
+    out, s = model(x.cuda(), [cb[0].cuda(), cb[1].cuda()], st, taps)
+    return out.cpu(), s[0].cpu()
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+def test_forward_vs_oracle_with_taps(hip_model, oracle, prec):
+    x, cb = make_inputs(4, 96, 160)
+    oracle.time_dims = 4
+    rt = {}
+    ro, rs = oracle(x, cb, None, rt)
+    ht = {}
+    ho, hs = _run_hip(hip_model, 4, prec, x, cb, None, ht)
+    scale = 10.0 if prec == "bf16x3" else 1.0
+    for k in ("c3", "c4", "c5", "sfnet", "st0", "st1", "fust_in_cb", "prefuse", "rnn"):
+        err = (ht[k].cpu() - rt[k]).abs().max().item()
+        assert err <= 2e-4 * scale, (k, prec, err)
+    assert (ht["logits"].cpu() - rt["logits"]).abs().max().item() <= LOGIT_TOL[prec]
+    assert (ho - ro).abs().max().item() <= MAP_TOL[prec]
+    assert (hs - rs[0]).abs().max().item() <= STATE_TOL[prec]
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+@pytest.mark.parametrize("name", ["e2e_96x160_T4", "e2e_96x160_B4T5", "e2e_96x160_T4_two_calls",
+                                  "e2e_72x104_T3", "e2e_288x512_T8", "e2e_360x640_T8"])
+def test_forward_vs_reference_golden(hip_model, golden_dir, name, prec):
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    H, W, T, B = int(g["H"]), int(g["W"]), int(g["T"]), int(g["B"])
+    n = B * T
+    state = None
+    for c in range(int(g["calls"])):
+        x, cb = make_inputs(n, H, W, int(g["seed"]), t0=c * n)
+        out, st = _run_hip(hip_model, T, prec, x, cb, state)
+        state = st
+        sfx = "" if c == 0 else f"_call{c}"
+        err = np.abs(out.numpy() - g["out" + sfx]).max()
+        assert err <= MAP_TOL[prec], (name, prec, c, err)
+        serr = np.abs(st.contiguous().view(-1).numpy()[::int(g["state_stride"])] - g["state" + sfx]).max()
+        assert serr <= STATE_TOL[prec], (name, prec, c, serr)
+
+
+def test_bf16_single_pass_error_is_reported(hip_model, oracle):
+    """Plain bf16 MFMA inputs do not meet 1e-3 in general; keep it bounded and visible."""
+    x, cb = make_inputs(4, 96, 160)
+    oracle.time_dims = 4
+    ro, _ = oracle(x, cb, None)
+    ho, _ = _run_hip(hip_model, 4, "bf16", x, cb)
+    err = (ho - ro).abs().max().item()
+    print("bf16 single-pass max-abs on the map: %.3e" % err)
+    assert err <= 0.15
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+def test_forward_clips_equals_independent_reference_calls(hip_model, oracle, prec):
+    C, T, H, W = 3, 3, 72, 104
+    x, cb = make_inputs(C * T, H, W)
+    h, w = H // 8, W // 8
+    xc = x.view(C, T, 3, H, W)
+    cbc = [cb[0].view(C, T, 8, h, w), cb[1].view(C, T, 20, h, w)]
+    g = torch.Generator().manual_seed(5)
+    st0 = torch.rand((C, 256, h, w), generator=g)
+    ro, rs = oracle.forward_clips(xc, cbc, st0)
+    hip_model.precision = prec
+    ho, hs = hip_model.forward_clips(xc.cuda(), [cbc[0].cuda(), cbc[1].cuda()], st0.cuda())
+    assert (ho.cpu() - ro).abs().max().item() <= MAP_TOL[prec]
+    assert (hs.cpu() - rs).abs().max().item() <= STATE_TOL[prec]
+
+
+def test_state_is_not_aliased_between_calls(hip_model):
+    """The caller re-feeds `[out_state[0].detach()]` (Demo_Test.py:86): a returned state must
+    stay valid after the next call."""
+    x, cb = make_inputs(4, 96, 160)
+    o1, s1 = _run_hip(hip_model, 4, "f32", x, cb)
+    keep = s1.clone()
+    x2, cb2 = make_inputs(4, 96, 160, t0=4)
+    _run_hip(hip_model, 4, "f32", x2, cb2, s1)
+    assert torch.equal(s1, keep)
+
+
+def test_uint8_frames_match_float_frames(hip_model):
+    u8 = synth.synth_frames_u8(4, 96, 160)
+    x, cb = make_inputs(4, 96, 160)
+    hip_model.time_dims, hip_model.precision = 4, "f32"
+    a, _ = hip_model(x.cuda(), [cb[0].cuda(), cb[1].cuda()], None)
+    b, _ = hip_model(torch.from_numpy(u8).cuda(), [cb[0].cuda(), cb[1].cuda()], None)
+    assert (a - b).abs().max().item() <= 1e-4
+
+
+def test_graph_replay_matches_launch_loop(hip_model):
+    x, cb = make_inputs(4, 96, 160)
+    a, sa = _run_hip(hip_model, 4, "bf16x3", x, cb)
+    hip_model.use_graph = True
+    try:
+        b, sb = _run_hip(hip_model, 4, "bf16x3", x, cb)
+        b2, _ = _run_hip(hip_model, 4, "bf16x3", x, cb)
+    finally:
+        hip_model.use_graph = False
+    assert torch.equal(a, b) and torch.equal(sa, sb) and torch.equal(a, b2)
+
+
+def test_error_behaviour(hip_model):
+    x, cb = make_inputs(4, 96, 160)
+    hip_model.time_dims = 4
+    with pytest.raises(RuntimeError):     # a single frame: the reference raises in teConv_sub
+        hip_model(x[:1].cuda(), [cb[0][:1].cuda(), cb[1][:1].cuda()], None)
+    with pytest.raises(RuntimeError):     # not a multiple of time_dims: x.view(B, T, ...) fails
+        hip_model(x[:3].cuda(), [cb[0][:3].cuda(), cb[1][:3].cuda()], None)
+    with pytest.raises(RuntimeError):     # wrong prior shape
+        hip_model(x.cuda(), [cb[0][:, :4].cuda(), cb[1].cuda()], None)
+    with pytest.raises(RuntimeError):     # CPU tensors: no fallback
+        hip_model(x, cb, None)

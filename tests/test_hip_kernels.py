@@ -1,0 +1,236 @@
+"""Per-kernel parity on the MI355X: every entry point of the C ABI against a plain
+PyTorch-CPU fp32 restatement of the same reference operator (F.conv2d / F.interpolate /
+slicing), on seeded inputs.  Tolerances are written next to each check:
+  f32    : exact-fp32 MFMA, only summation order differs      -> 2e-5 * scale
+  bf16x3 : split-bf16 (hi*hi + hi*lo + lo*hi), ~2^-16 relative -> 2e-4 * scale
+  bf16   : single bf16 MFMA, ~2^-8 relative                    -> 3e-2 * scale
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"f32": 2e-5, "bf16x3": 2e-4, "bf16": 3e-2}
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from iip_uavsal_saliency_amd import ops as o
+    return o
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(shape, generator=g) * 2 - 1) * scale
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous().cpu()
+
+
+def act_ref(y, act):
+    if act == 1:
+        return torch.clamp(y, 0, 6)
+    if act == 2:
+        return torch.sigmoid(y)
+    return y
+
+
+CONV1_CASES = [
+    # n, h, w, cin, cout, act, res
+    (2, 5, 7, 8, 48, 1, False),        # gauss prior expand (Cin=8 < K tile)
+    (2, 5, 7, 20, 120, 1, False),      # observed prior expand (Cin=20, ragged K tile)
+    (1, 9, 13, 32, 16, 0, False),      # features.1 pw-linear, Cout < 32
+    (2, 12, 20, 96, 24, 0, False),
+    (1, 12, 20, 144, 24, 0, True),     # residual
+    (2, 12, 20, 256, 1536, 1, False),  # big N
+    (1, 23, 40, 1536, 256, 0, True),   # big K
+    (2, 12, 20, 1536, 1, 2, False),    # decoder: Cout=1 + sigmoid
+    (3, 7, 5, 320, 256, 1, False),
+    (1, 45, 80, 32, 256, 1, True),     # te last_conv + x_sp
+]
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3", "bf16"])
+@pytest.mark.parametrize("case", CONV1_CASES)
+def test_conv1x1(ops, prec, case):
+    n, h, w, cin, cout, act, use_res = case
+    x = rnd((n, cin, h, w), 1, 2.0)
+    wt = rnd((cout, cin, 1, 1), 2, 1.0 / np.sqrt(cin))
+    scale = rnd((cout,), 3) * 0.5 + 1.0
+    bias = rnd((cout,), 4)
+    res = rnd((n, cout, h, w), 5) if use_res else None
+    ref = act_ref(F.conv2d(x, wt) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1), act)
+    if use_res:
+        ref = ref + res
+    got = ops.conv_gemm(nhwc(x), wt, scale, bias, act=act, res=nhwc(res) if use_res else None, prec=prec)
+    err = (nchw(got) - ref).abs().max().item()
+    assert err <= TOL[prec] * 4.0, (case, prec, err)
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3, 4])
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+def test_conv1x1_all_tiles(ops, prec, tile):
+    n, h, w, cin, cout = 2, 11, 13, 64, 160      # M = 286: ragged against every tile height
+    x = rnd((n, cin, h, w), 11, 2.0)
+    wt = rnd((cout, cin, 1, 1), 12, 1.0 / 8)
+    ref = F.conv2d(x, wt)
+    got = ops.conv_gemm(nhwc(x), wt, None, None, prec=prec, tile=tile)
+    err = (nchw(got) - ref).abs().max().item()
+    assert err <= TOL[prec] * 4.0, (tile, prec, err)
+
+
+def test_conv1x1_channel_slices(ops):
+    """Reading from and writing into channel slices of wider buffers (how torch.cat disappears)."""
+    n, h, w = 2, 6, 9
+    wide_in = nhwc(rnd((n, 96, h, w), 21))
+    wt = rnd((64, 32, 1, 1), 22, 0.2)
+    wide_out = torch.full((n, h, w, 192), -7.0, device="cuda")
+    ops.conv_gemm(wide_in[..., 32:64], wt, None, None, out=wide_out[..., 64:128])
+    ref = F.conv2d(nchw(wide_in)[:, 32:64], wt)
+    assert (nchw(wide_out)[:, 64:128] - ref).abs().max().item() <= 1e-4
+    assert torch.all(wide_out[..., :64] == -7.0) and torch.all(wide_out[..., 128:] == -7.0)
+
+
+CONV3_CASES = [(1, 9, 13, 32, 64), (2, 12, 20, 448, 256), (1, 45, 80, 256, 256), (3, 5, 4, 64, 32)]
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3", "bf16"])
+@pytest.mark.parametrize("case", CONV3_CASES)
+def test_conv3x3(ops, prec, case):
+    n, h, w, cin, cout = case
+    x = rnd((n, cin, h, w), 31, 2.0)
+    wt = rnd((cout, cin, 3, 3), 32, 1.0 / np.sqrt(9 * cin))
+    scale = rnd((cout,), 33) * 0.5 + 1.0
+    bias = rnd((cout,), 34)
+    ref = torch.clamp(F.conv2d(x, wt, padding=1) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1), 0, 6)
+    got = ops.conv_gemm(nhwc(x), wt, scale, bias, act=1, prec=prec)
+    err = (nchw(got) - ref).abs().max().item()
+    assert err <= TOL[prec] * 4.0, (case, prec, err)
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+def test_twa_step(ops, prec):
+    """ConvTWACell.forward (model_convlstm.py:276-292) with the x half of the conv hoisted."""
+    n, c, h, w = 2, 256, 12, 20
+    x = rnd((n, c, h, w), 41, 2.0)
+    hp = rnd((n, c, h, w), 42, 2.0)
+    wt = rnd((c, 2 * c, 3, 3), 43, 1.0 / np.sqrt(9 * 2 * c))
+    gate = torch.sigmoid(F.conv2d(torch.cat([x, hp], 1), wt, padding=1))
+    ref = gate * x + (1 - gate) * hp
+    pre = ops.conv_gemm(nhwc(x), wt[:, :c].contiguous(), None, None, prec=prec)
+    got = ops.twa_step(nhwc(x), nhwc(hp), pre, wt[:, c:].contiguous(), prec=prec)
+    err = (nchw(got) - ref).abs().max().item()
+    assert err <= TOL[prec] * 4.0, (prec, err)
+
+
+DW_CASES = [
+    # n, h, w, c, stride, dilation
+    (2, 9, 13, 48, 1, 1), (1, 12, 20, 120, 1, 1), (2, 45, 80, 1536, 1, 1), (1, 23, 41, 96, 2, 1),
+    (2, 45, 80, 1536, 2, 1), (1, 180, 320, 32, 1, 1), (2, 12, 20, 1920, 1, 6), (2, 12, 20, 1920, 1, 12),
+    (2, 12, 20, 1920, 1, 18), (1, 5, 3, 144, 2, 1), (1, 1, 1, 64, 1, 1), (1, 2, 2, 64, 2, 1),
+]
+
+
+@pytest.mark.parametrize("case", DW_CASES)
+def test_depthwise(ops, case):
+    n, h, w, c, stride, dil = case
+    x = rnd((n, c, h, w), 51, 2.0)
+    wt = rnd((c, 1, 3, 3), 52, 0.4)
+    scale = rnd((c,), 53) * 0.5 + 1.0
+    bias = rnd((c,), 54)
+    ref = torch.clamp(F.conv2d(x, wt, stride=stride, padding=dil, dilation=dil, groups=c)
+                      * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1), 0, 6)
+    got = ops.dw3x3(nhwc(x), wt, scale, bias, stride=stride, dilation=dil)
+    assert tuple(got.shape) == (n, ref.shape[2], ref.shape[3], c)
+    err = (nchw(got) - ref).abs().max().item()
+    assert err <= 1e-5, (case, err)       # 9 fp32 fmas per output, order may differ
+
+
+@pytest.mark.parametrize("size", [(2, 36, 64), (1, 45, 81), (2, 7, 9)])
+def test_stem(ops, size):
+    n, H, W = size
+    x = rnd((n, 3, H, W), 61, 2.0)
+    wt = rnd((32, 3, 3, 3), 62, 0.3)
+    scale = rnd((32,), 63) * 0.5 + 1.0
+    bias = rnd((32,), 64)
+    ref = torch.clamp(F.conv2d(x, wt, stride=2, padding=1) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1), 0, 6)
+    got = ops.stem_conv(x.cuda(), wt, scale, bias)
+    assert (nchw(got) - ref).abs().max().item() <= 2e-5
+
+
+def test_stem_uint8_normalisation(ops):
+    """uint8 frames normalised on load == normalize_data (utils_data.py:43-65) then the fp32 stem."""
+    from iip_uavsal_saliency_amd import synth
+    u8 = synth.synth_frames_u8(2, 24, 40)
+    wt = rnd((32, 3, 3, 3), 62, 0.3)
+    scale = rnd((32,), 63) * 0.5 + 1.0
+    bias = rnd((32,), 64)
+    a = ops.stem_conv(torch.from_numpy(synth.normalize_frames(u8)).cuda(), wt, scale, bias)
+    b = ops.stem_conv(torch.from_numpy(u8).cuda(), wt, scale, bias)
+    assert (a - b).abs().max().item() <= 2e-5
+
+
+@pytest.mark.parametrize("case", [(2, 12, 20, 256, 45, 80), (1, 23, 40, 128, 45, 80), (2, 3, 5, 64, 12, 20), (1, 1, 1, 8, 4, 4)])
+def test_bilinear_align_corners(ops, case):
+    n, hi, wi, c, ho, wo = case
+    x = rnd((n, c, hi, wi), 71)
+    ref = F.interpolate(x, size=(ho, wo), mode="bilinear", align_corners=True)
+    got = ops.bilinear_ac(nhwc(x), ho, wo)
+    assert (nchw(got) - ref).abs().max().item() <= 2e-6
+
+
+def test_bilinear_context_maps(ops):
+    """`cb_cxt.repeat(T,1,1,1)` tiling (model.py:361) and the per-clip map of forward_clips."""
+    B, T, c = 3, 4, 64
+    x = rnd((B, c, 3, 5), 72)
+    up = F.interpolate(x, size=(12, 20), mode="bilinear", align_corners=True)
+    tiled = up.repeat(T, 1, 1, 1)                                 # frame k <- chunk k % B
+    got = ops.bilinear_ac(nhwc(x), 12, 20, n_out=B * T, src_mod=B, src_div=1)
+    assert (nchw(got) - tiled).abs().max().item() <= 2e-6
+    per_clip = up.repeat_interleave(T, 0)                         # frame (c,t) <- clip c
+    got = ops.bilinear_ac(nhwc(x), 12, 20, n_out=B * T, src_mod=B * T, src_div=T)
+    assert (nchw(got) - per_clip).abs().max().item() <= 2e-6
+
+
+@pytest.mark.parametrize("n,L", [(5, 5), (6, 3), (2, 2), (8, 4)])
+def test_temporal_differences(ops, n, L):
+    from oracle.uavsal_ref import temporal_differences
+    x = rnd((n, 32, 6, 7), 81)
+    ref = torch.cat([temporal_differences(x[i:i + L]) for i in range(0, n, L)], 0)
+    got = ops.tdiff(nhwc(x), L)
+    assert torch.equal(nchw(got), ref)     # single fp32 subtraction: bit-exact
+
+
+def test_time_sum(ops):
+    x = rnd((8, 256, 5, 6), 91)
+    ref = x.view(2, 4, 256, 5, 6).sum(1)
+    got = ops.tsum(nhwc(x), 4)
+    assert (nchw(got) - ref).abs().max().item() <= 1e-6
+
+
+@pytest.mark.parametrize("c,hw", [(8, (45, 80)), (20, (12, 20)), (256, (9, 13)), (3, (5, 5))])
+def test_layout_roundtrip(ops, c, hw):
+    x = rnd((2, c, hw[0], hw[1]), 95)
+    y = ops.to_nhwc(x.cuda())
+    assert torch.equal(y.cpu(), x.permute(0, 2, 3, 1).contiguous())
+    z = ops.to_nchw(y)
+    assert torch.equal(z.cpu(), x)
+
+
+def test_rejects_bad_arguments(ops):
+    x = torch.zeros((1, 4, 4, 6), device="cuda")          # Cin % 4 != 0
+    with pytest.raises(RuntimeError):
+        ops.conv_gemm(x, torch.zeros(8, 6, 1, 1), None, None)
+    with pytest.raises(RuntimeError):                      # 3x3 needs Cin % 32 == 0
+        ops.conv_gemm(torch.zeros((1, 4, 4, 16), device="cuda"), torch.zeros(8, 16, 3, 3), None, None)
+    with pytest.raises(RuntimeError):                      # one frame: reference raises too (model.py:194)
+        ops.tdiff(torch.zeros((1, 4, 4, 32), device="cuda"), 1)
