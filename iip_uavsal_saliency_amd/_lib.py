@@ -11,7 +11,7 @@ import os
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG, "libuavsal_hip.so")
 
-PREC = {"f32": 0, "bf16x3": 1, "bf16": 2}
+PREC = {"f32": 0, "bf16x3": 1, "bf16": 2, "f16x3": 3}
 ACT_NONE, ACT_RELU6, ACT_SIGMOID = 0, 1, 2
 EPI_AFFINE, EPI_TWA = 0, 1
 

@@ -52,18 +52,44 @@ __device__ __forceinline__ long long row_off(int m, int HW, long long img_stride
     return (long long)img * img_stride + (m - img * HW);
 }
 
-__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
-    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+// F16X3 pre-scales: activations by 2^4 while staging (saturating at the fp16 range, i.e.
+// |x| > 4094 clips), weights by 2^6 on the host; the accumulator is scaled back by 2^-10.
+// Powers of two, so nothing is rounded by the scaling itself; it only keeps the low halves
+// of the split away from the fp16 subnormal range.
+#define F16X3_A_SCALE 16.0f
+#define F16X3_ACC_SCALE (1.0f / 1024.0f)
+
+template <int PREC>
+__device__ __forceinline__ unsigned pack2(float a, float b) {
     typedef float f2 __attribute__((ext_vector_type(2)));
     f2 v = {a, b};
-    bf2 r = __builtin_convertvector(v, bf2);
-    return __builtin_bit_cast(unsigned, r);
+    if (PREC == UAVSAL_PREC_F16X3) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        h2 r = __builtin_convertvector(v, h2);
+        return __builtin_bit_cast(unsigned, r);
+    } else {
+        typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+        bf2 r = __builtin_convertvector(v, bf2);
+        return __builtin_bit_cast(unsigned, r);
+    }
 }
 
-__device__ __forceinline__ float bf16_hi_as_f32(float x) {
-    // value of bf16(x) as fp32 (round to nearest even), via the same conversion as the pack
+// value of the 16-bit rounding of x, as fp32 (same conversion as pack2)
+template <int PREC>
+__device__ __forceinline__ float hi_as_f32(float x) {
+    if (PREC == UAVSAL_PREC_F16X3) { _Float16 h = (_Float16)x; return (float)h; }
     __bf16 h = (__bf16)x;
     return (float)h;
+}
+
+template <int PREC>
+__device__ __forceinline__ f32x4 prescale(f32x4 x) {
+    if (PREC == UAVSAL_PREC_F16X3) {
+        x = x * F16X3_A_SCALE;
+        x.x = fminf(fmaxf(x.x, -65504.f), 65504.f); x.y = fminf(fmaxf(x.y, -65504.f), 65504.f);
+        x.z = fminf(fmaxf(x.z, -65504.f), 65504.f); x.w = fminf(fmaxf(x.w, -65504.f), 65504.f);
+    }
+    return x;
 }
 
 template <int PREC, int WAVES_M, int WAVES_N, int WM, int WN, int TAPS>
@@ -71,7 +97,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvK p) {
     constexpr int BM = WAVES_M * WM * 32;
     constexpr int BN = WAVES_N * WN * 32;
     constexpr int KT = (PREC == UAVSAL_PREC_F32) ? 16 : 32;
-    constexpr int NPAN = (PREC == UAVSAL_PREC_BF16X3) ? 2 : 1;
+    constexpr int NPAN = (PREC == UAVSAL_PREC_BF16X3 || PREC == UAVSAL_PREC_F16X3) ? 2 : 1;
     constexpr int NLD = (PREC == UAVSAL_PREC_F32) ? 1 : 2;   // float4 loads per A chunk
     constexpr int A_IT = (BM * 4) / 256;
     constexpr int B_IT = (BN * 4 + 255) / 256;
@@ -172,17 +198,17 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvK p) {
             if (PREC == UAVSAL_PREC_F32) {
                 *reinterpret_cast<f32x4*>(As + slot) = a_reg[it][0];
             } else {
-                const f32x4 x0 = a_reg[it][0], x1 = a_reg[it][NLD - 1];
+                const f32x4 x0 = prescale<PREC>(a_reg[it][0]), x1 = prescale<PREC>(a_reg[it][NLD - 1]);
                 u32x4 hi;
-                hi.x = pack_bf16x2(x0.x, x0.y); hi.y = pack_bf16x2(x0.z, x0.w);
-                hi.z = pack_bf16x2(x1.x, x1.y); hi.w = pack_bf16x2(x1.z, x1.w);
+                hi.x = pack2<PREC>(x0.x, x0.y); hi.y = pack2<PREC>(x0.z, x0.w);
+                hi.z = pack2<PREC>(x1.x, x1.y); hi.w = pack2<PREC>(x1.z, x1.w);
                 *reinterpret_cast<u32x4*>(As + slot) = hi;
-                if (PREC == UAVSAL_PREC_BF16X3) {
+                if (NPAN == 2) {
                     u32x4 lo;
-                    lo.x = pack_bf16x2(x0.x - bf16_hi_as_f32(x0.x), x0.y - bf16_hi_as_f32(x0.y));
-                    lo.y = pack_bf16x2(x0.z - bf16_hi_as_f32(x0.z), x0.w - bf16_hi_as_f32(x0.w));
-                    lo.z = pack_bf16x2(x1.x - bf16_hi_as_f32(x1.x), x1.y - bf16_hi_as_f32(x1.y));
-                    lo.w = pack_bf16x2(x1.z - bf16_hi_as_f32(x1.z), x1.w - bf16_hi_as_f32(x1.w));
+                    lo.x = pack2<PREC>(x0.x - hi_as_f32<PREC>(x0.x), x0.y - hi_as_f32<PREC>(x0.y));
+                    lo.y = pack2<PREC>(x0.z - hi_as_f32<PREC>(x0.z), x0.w - hi_as_f32<PREC>(x0.w));
+                    lo.z = pack2<PREC>(x1.x - hi_as_f32<PREC>(x1.x), x1.y - hi_as_f32<PREC>(x1.y));
+                    lo.w = pack2<PREC>(x1.z - hi_as_f32<PREC>(x1.z), x1.w - hi_as_f32<PREC>(x1.w));
                     *reinterpret_cast<u32x4*>(As + APAN + slot) = lo;
                 }
             }
@@ -246,6 +272,14 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvK p) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[i][j], 0, 0, 0);
+                    } else if (PREC == UAVSAL_PREC_F16X3) {
+                        const f16x8 ah = __builtin_bit_cast(f16x8, af[i][0]);
+                        const f16x8 bh = __builtin_bit_cast(f16x8, bfr[j][0]);
+                        const f16x8 al = __builtin_bit_cast(f16x8, af[i][NPAN - 1]);
+                        const f16x8 bl = __builtin_bit_cast(f16x8, bfr[j][NPAN - 1]);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[i][j], 0, 0, 0);
                     } else {
                         const bf16x8 ah = __builtin_bit_cast(bf16x8, af[i][0]);
                         const bf16x8 bh = __builtin_bit_cast(bf16x8, bfr[j][0]);
@@ -293,6 +327,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvK p) {
                 const int n = n0 + (wn * WN + j) * 32 + lr;
                 if (n >= p.Cout) continue;
                 float vv = acc[i][j][g];
+                if (PREC == UAVSAL_PREC_F16X3) vv *= F16X3_ACC_SCALE;
                 if (p.epi == UAVSAL_EPI_TWA) {
                     const float z = vv + p.aux[xo + n];
                     const float gate = 1.f / (1.f + expf(-z));
@@ -313,7 +348,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvK p) {
 template <int PREC, int WAVES_M, int WAVES_N, int WM, int WN>
 int launch_variant(const ConvK& k0, int taps, hipStream_t stream) {
     constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32;
-    constexpr int NPAN = (PREC == UAVSAL_PREC_BF16X3) ? 2 : 1;
+    constexpr int NPAN = (PREC == UAVSAL_PREC_BF16X3 || PREC == UAVSAL_PREC_F16X3) ? 2 : 1;
     constexpr int SMEM = 2 * NPAN * (BM + BN) * 64;
     ConvK k = k0;
     const int tiles_m = (k.M + BM - 1) / BM;
@@ -357,7 +392,7 @@ extern "C" int uavsal_conv_gemm(const uavsal_conv_desc* d, uavsal_stream_t strea
     if (!d || !d->a || !d->w || !d->out) return UAVSAL_EINVAL;
     if (d->n_img <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0) return UAVSAL_EINVAL;
     if (d->taps != 1 && d->taps != 9) return UAVSAL_ESHAPE;
-    if (d->prec < 0 || d->prec > 2) return UAVSAL_ESHAPE;
+    if (d->prec < 0 || d->prec > 3) return UAVSAL_ESHAPE;
     if ((d->Cin & 3) || (d->lda & 3) || d->lda < d->Cin) return UAVSAL_EALIGN;
     if (d->ldc < d->Cout) return UAVSAL_ESHAPE;
     if (!uavsal_aligned16(d->a) || !uavsal_aligned16(d->w)) return UAVSAL_EALIGN;
@@ -393,6 +428,7 @@ extern "C" int uavsal_conv_gemm(const uavsal_conv_desc* d, uavsal_stream_t strea
     switch (d->prec) {
         case UAVSAL_PREC_F32: return launch_prec<UAVSAL_PREC_F32>(k, d->taps, tile, s);
         case UAVSAL_PREC_BF16X3: return launch_prec<UAVSAL_PREC_BF16X3>(k, d->taps, tile, s);
+        case UAVSAL_PREC_F16X3: return launch_prec<UAVSAL_PREC_F16X3>(k, d->taps, tile, s);
         default: return launch_prec<UAVSAL_PREC_BF16>(k, d->taps, tile, s);
     }
 }

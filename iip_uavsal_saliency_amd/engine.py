@@ -425,12 +425,21 @@ class Engine:
     def launch(self):
         """Launch the recorded plan once on torch's current stream (no staging, no sync)."""
         if self.use_graph:
+            # the legacy default stream cannot be captured: capture and replay on a private
+            # stream, fenced against torch's current stream on both sides
+            cur = torch.cuda.current_stream(self.device)
             if not self._graph_ready:
-                L.check(self.lib.uavsal_plan_run(self.plan, 0, -1, self._stream()), "plan_run (warm-up)")
-                torch.cuda.current_stream(self.device).synchronize()
-                L.check(self.lib.uavsal_plan_graph_build(self.plan, self._stream()), "plan_graph_build")
+                self._gstream = torch.cuda.Stream(self.device)
+                self._gstream.wait_stream(cur)
+                gs = C.c_void_p(self._gstream.cuda_stream)
+                L.check(self.lib.uavsal_plan_run(self.plan, 0, -1, gs), "plan_run (warm-up)")
+                self._gstream.synchronize()
+                L.check(self.lib.uavsal_plan_graph_build(self.plan, gs), "plan_graph_build")
                 self._graph_ready = True
-            L.check(self.lib.uavsal_plan_graph_launch(self.plan, self._stream()), "plan_graph_launch")
+            self._gstream.wait_stream(cur)
+            L.check(self.lib.uavsal_plan_graph_launch(self.plan, C.c_void_p(self._gstream.cuda_stream)),
+                    "plan_graph_launch")
+            cur.wait_stream(self._gstream)
         else:
             L.check(self.lib.uavsal_plan_run(self.plan, 0, -1, self._stream()), "plan_run")
 

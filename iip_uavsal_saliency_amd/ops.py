@@ -23,8 +23,11 @@ def _nhwc_view(t: torch.Tensor):
     if t.dim() != 4 or t.dtype != torch.float32 or not t.is_cuda:
         raise RuntimeError("expected a float32 cuda NHWC tensor [n,h,w,c]")
     n, h, w, c = t.shape
-    ld = t.stride(2)
-    if t.stride(3) != 1 or t.stride(1) != w * ld or t.stride(0) != h * w * ld:
+    # strides of size-1 dimensions are arbitrary in torch: take ld from the first real one
+    ld = t.stride(2) if w > 1 else (t.stride(1) if h > 1 else (t.stride(0) if n > 1 else c))
+    ok = (c == 1 or t.stride(3) == 1) and (w == 1 or t.stride(2) == ld) \
+        and (h == 1 or t.stride(1) == w * ld) and (n == 1 or t.stride(0) == h * w * ld)
+    if not ok:
         raise RuntimeError("tensor is not an NHWC buffer (or channel slice of one)")
     return t.data_ptr(), ld, n, h, w, c
 

@@ -36,7 +36,7 @@ def roundup(x: int, m: int) -> int:
 
 def pack_conv_weight(w: torch.Tensor, prec: str) -> torch.Tensor:
     """`w` [Cout, Cin, kh, kw] (kh=kw in {1,3}) -> packed byte tensor (uint8, 1-D) in the layout
-    `uavsal_conv_gemm` expects for `prec` in {'f32','bf16','bf16x3'}."""
+    `uavsal_conv_gemm` expects for `prec` in {'f32','bf16','bf16x3','f16x3'}."""
     w = w.detach().float().cpu()
     cout, cin, kh, kw = w.shape
     taps = kh * kw
@@ -52,6 +52,11 @@ def pack_conv_weight(w: torch.Tensor, prec: str) -> torch.Tensor:
         return m.contiguous().view(torch.uint8).reshape(-1)
     idx = torch.tensor(_K_PERM32, dtype=torch.long)
     m = m.view(npad, kpad // 32, 32)[:, :, idx].reshape(npad, kpad)
+    if prec == "f16x3":
+        m = m * 64.0
+        hi = m.to(torch.float16)
+        lo = (m - hi.float()).to(torch.float16)
+        return torch.stack([hi, lo], 0).contiguous().view(torch.uint8).reshape(-1)
     hi = m.to(torch.bfloat16)
     if prec == "bf16":
         return hi.contiguous().view(torch.uint8).reshape(-1)

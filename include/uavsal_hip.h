@@ -47,6 +47,8 @@ extern "C" {
 #define UAVSAL_PREC_F32     0 /* v_mfma_f32_32x32x2_f32: exact fp32 fma chain */
 #define UAVSAL_PREC_BF16X3  1 /* 3x v_mfma_f32_32x32x16_bf16 on a hi/lo bf16 split, fp32 accumulate */
 #define UAVSAL_PREC_BF16    2 /* 1x bf16 MFMA, fp32 accumulate */
+#define UAVSAL_PREC_F16X3   3 /* 3x v_mfma_f32_32x32x16_f16 on a hi/lo fp16 split (22 mantissa bits), fp32 accumulate;
+                                 activations are pre-scaled by 2^4 (|x| > 4094 saturates), weights by 2^6 */
 
 #define UAVSAL_ACT_NONE     0
 #define UAVSAL_ACT_RELU6    1 /* nn.ReLU6, model.py:71 */
@@ -78,11 +80,12 @@ typedef void* uavsal_stream_t;
  *
  * Weights `w` are pre-packed by the host (iip_uavsal_saliency_amd/packing.py):
  *   k index = tap * Cin + ci, rows padded to Npad = roundup(Cout, 32), K padded to
- *   Kpad = roundup(taps * Cin, KT) with zeros, KT = 16 (F32) or 32 (BF16*);
+ *   Kpad = roundup(taps * Cin, KT) with zeros, KT = 16 (F32) or 32 (BF16*, F16X3);
  *   F32:    float  [Npad][Kpad]
  *   BF16:   uint16 [Npad][Kpad]            (bf16 bits, round-to-nearest-even)
  *   BF16X3: uint16 hi[Npad][Kpad] then uint16 lo[Npad][Kpad], lo = bf16(w - hi)
- *   in the BF16* layouts each group of 32 k's is stored in the order
+ *   F16X3:  as BF16X3 with fp16 bits of ws = 64*w: hi = fp16(ws), lo = fp16(ws - hi)
+ *   in the BF16* / F16X3 layouts each group of 32 k's is stored in the order
  *   {0-3,16-19, 4-7,20-23, 8-11,24-27, 12-15,28-31} (matches the A staging).
  * taps == 9 requires Cin % 32 == 0.
  */

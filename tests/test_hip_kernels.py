@@ -2,6 +2,7 @@
 PyTorch-CPU fp32 restatement of the same reference operator (F.conv2d / F.interpolate /
 slicing), on seeded inputs.  Tolerances are written next to each check:
   f32    : exact-fp32 MFMA, only summation order differs      -> 2e-5 * scale
+  f16x3  : split-fp16 (hi*hi + hi*lo + lo*hi), ~2^-21 relative -> 2e-5 * scale
   bf16x3 : split-bf16 (hi*hi + hi*lo + lo*hi), ~2^-16 relative -> 2e-4 * scale
   bf16   : single bf16 MFMA, ~2^-8 relative                    -> 3e-2 * scale
 """
@@ -12,7 +13,7 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-TOL = {"f32": 2e-5, "bf16x3": 2e-4, "bf16": 3e-2}
+TOL = {"f32": 2e-5, "f16x3": 2e-5, "bf16x3": 2e-4, "bf16": 3e-2}
 
 
 @pytest.fixture(scope="module")
@@ -59,7 +60,7 @@ CONV1_CASES = [
 ]
 
 
-@pytest.mark.parametrize("prec", ["f32", "bf16x3", "bf16"])
+@pytest.mark.parametrize("prec", ["f32", "f16x3", "bf16x3", "bf16"])
 @pytest.mark.parametrize("case", CONV1_CASES)
 def test_conv1x1(ops, prec, case):
     n, h, w, cin, cout, act, use_res = case
@@ -77,7 +78,7 @@ def test_conv1x1(ops, prec, case):
 
 
 @pytest.mark.parametrize("tile", [1, 2, 3, 4])
-@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+@pytest.mark.parametrize("prec", ["f32", "f16x3", "bf16x3"])
 def test_conv1x1_all_tiles(ops, prec, tile):
     n, h, w, cin, cout = 2, 11, 13, 64, 160      # M = 286: ragged against every tile height
     x = rnd((n, cin, h, w), 11, 2.0)
@@ -103,7 +104,7 @@ def test_conv1x1_channel_slices(ops):
 CONV3_CASES = [(1, 9, 13, 32, 64), (2, 12, 20, 448, 256), (1, 45, 80, 256, 256), (3, 5, 4, 64, 32)]
 
 
-@pytest.mark.parametrize("prec", ["f32", "bf16x3", "bf16"])
+@pytest.mark.parametrize("prec", ["f32", "f16x3", "bf16x3", "bf16"])
 @pytest.mark.parametrize("case", CONV3_CASES)
 def test_conv3x3(ops, prec, case):
     n, h, w, cin, cout = case
@@ -117,7 +118,7 @@ def test_conv3x3(ops, prec, case):
     assert err <= TOL[prec] * 4.0, (case, prec, err)
 
 
-@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+@pytest.mark.parametrize("prec", ["f32", "f16x3", "bf16x3"])
 def test_twa_step(ops, prec):
     """ConvTWACell.forward (model_convlstm.py:276-292) with the x half of the conv hoisted."""
     n, c, h, w = 2, 256, 12, 20
@@ -224,6 +225,14 @@ def test_layout_roundtrip(ops, c, hw):
     assert torch.equal(y.cpu(), x.permute(0, 2, 3, 1).contiguous())
     z = ops.to_nchw(y)
     assert torch.equal(z.cpu(), x)
+
+
+def test_f16x3_saturates_instead_of_overflowing(ops):
+    """|x| * 16 beyond the fp16 range clips (documented in uavsal_hip.h) -- never inf/nan."""
+    x = torch.full((1, 32, 4, 4), 1.0e5)
+    wt = torch.full((32, 32, 1, 1), 0.01)
+    got = ops.conv_gemm(nhwc(x), wt, None, None, prec="f16x3")
+    assert torch.isfinite(got).all()
 
 
 def test_rejects_bad_arguments(ops):
