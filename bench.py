@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""Benchmark of the UAVSal HIP path: saliency frames/s at 360x640 on N MI355X.
+
+A "step" is one pass of the hot path (`UAVSal.forward_clips`) over one batch of
+synthetic clips that are already resident in HBM.  Default workload (N=1) is
+BASELINE.json configs[1]: 360x640, batch=1 clip, seq=8 frames, exact-fp32 MFMA.
+For N>1 every rank runs the same per-GPU workload on its own clips (weak
+scaling, clips are independent) and the output maps are exchanged with ONE RCCL
+all-gather per step.  Rank 0 prints one JSON line.
+
+Extra objects on that line:
+  roofline      dominant kernel (largest summed device time): algorithmic FLOP/s
+                (or bytes/s) per launch / average launch duration measured with
+                hipEvents on the launch stream, against the MI355X peak.
+  roofline_dw   the depthwise 3x3 kernel against the HBM roofline (north_star
+                asks >= 60 %), algorithmic bytes per SURVEY.md 8(d).
+  cpu_baseline  the oracle (CPU restatement, torch fp32) timed on this box's
+                host cores on ONE clip of the same workload (bounded sample).
+  parity        max-abs of the saliency map vs that CPU run on the same inputs.
+  extra         BASELINE.json configs[2]-shaped run (8 clips, split-fp16 MFMA, hipGraph).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+PEAK_TFLOPS = {"f32": 157.3, "f16x3": 2500.0 / 3, "bf16x3": 2500.0 / 3, "bf16": 2500.0}   # dense; MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+DTYPE_NAME = {"f32": "f32", "f16x3": "f32 (3x f16 split MFMA, f32 accumulate)",
+              "bf16x3": "f32 (3x bf16 split MFMA, f32 accumulate)", "bf16": "bf16"}
+TILE_NAME = {1: "128x128", 2: "128x64", 3: "128x32", 4: "64x64"}
+
+
+def make_clips(C, T, H, W, seed=0):
+    from iip_uavsal_saliency_amd import synth
+    h, w = H // 8, W // 8
+    xs, g, o = [], [], []
+    for c in range(C):
+        xs.append(torch.from_numpy(synth.normalize_frames(synth.synth_frames_u8(T, H, W, seed + c))))
+        g.append(torch.from_numpy(synth.gauss_priors(T, h, w)))
+        o.append(torch.from_numpy(synth.ob_priors(T, h, w, seed=seed + c)))
+    return torch.stack(xs), [torch.stack(g), torch.stack(o)]
+
+
+def kernel_rooflines(eng, prec, iters=5):
+    """Per-op device time (hipEvents on the launch stream) grouped by kernel instance."""
+    groups = {}
+    for i, m in enumerate(eng.ops_meta):
+        ms = eng.time_ops(i, i + 1, iters)
+        if m["kind"].startswith("conv"):
+            key = "conv_gemm_kernel<%s,%s,taps=%d>" % (prec, TILE_NAME[m["tile"]], 9 if m["kind"] == "conv3" else 1)
+        else:
+            key = m["kind"]
+        g = groups.setdefault(key, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0, "kind": m["kind"]})
+        g["ms"] += ms
+        g["flops"] += m["flops"]
+        g["bytes"] += m["bytes"]
+        g["launches"] += 1
+    return groups
+
+
+def roofline_obj(name, g, prec):
+    sec = g["ms"] * 1e-3
+    if g["kind"].startswith("conv"):
+        ach = g["flops"] / sec / 1e12
+        peak = PEAK_TFLOPS[prec]
+        return {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                "frac": round(ach / peak, 4), "traffic": None, "launches_per_step": g["launches"],
+                "avg_launch_us": round(g["ms"] * 1e3 / g["launches"], 2),
+                "alg_gflop_per_launch": round(g["flops"] / g["launches"] / 1e9, 3)}
+    ach = g["bytes"] / sec / 1e9
+    return {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None, "launches_per_step": g["launches"],
+            "avg_launch_us": round(g["ms"] * 1e3 / g["launches"], 2),
+            "alg_mb_per_launch": round(g["bytes"] / g["launches"] / 1e6, 3)}
+
+
+def timed_steps(fn, steps, warmup, distributed, device):
+    for _ in range(warmup):
+        fn()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize(device)
+    if distributed:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--clips", type=int, default=1, help="clips per GPU (BASELINE configs[1]: 1)")
+    ap.add_argument("--frames", type=int, default=8)
+    ap.add_argument("--height", type=int, default=360)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--prec", default="f32", choices=["f32", "f16x3", "bf16x3", "bf16"])
+    ap.add_argument("--graph", type=int, default=1, help="replay the launch plan as one hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if distributed and args.gpus != world:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU path to measure")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from iip_uavsal_saliency_amd import UAVSal, synth
+    from iip_uavsal_saliency_amd.parallel import ClipShard, gather_maps
+
+    C, T, H, W = args.clips, args.frames, args.height, args.width
+    h, w = H // 8, W // 8
+    shard = ClipShard(total_clips=C * world, world_size=world, rank=rank)
+    model = UAVSal(time_dims=T, precision=args.prec)
+    synth.load_synth_weights(model, 0)
+    model = model.to(device).eval()
+    model.use_graph = bool(args.graph)
+
+    x_cpu, cb_cpu = make_clips(C, T, H, W, seed=shard.first)       # this rank's clips
+    x = x_cpu.to(device)
+    cb = [cb_cpu[0].to(device), cb_cpu[1].to(device)]
+    state = torch.zeros((C, 256, h, w), device=device)
+    gathered = torch.empty((C * world, T, 1, h, w), device=device) if distributed else None
+    last = {}
+
+    def step():
+        out, st = model.forward_clips(x, cb, state)
+        if distributed:
+            gather_maps(out, gathered)
+        last["out"], last["state"] = out, st
+
+    dt = timed_steps(step, args.steps, args.warmup, distributed, device)
+    frames = C * T * world * args.steps
+    fps = frames / dt
+    result = {
+        "metric": "saliency frames/sec at 360x640" if (H, W) == (360, 640) else "saliency frames/sec at %dx%d" % (H, W),
+        "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": DTYPE_NAME[args.prec], "data": "synthetic",
+        "config": {"workload": "%dx%d batch=%d clip(s)/GPU seq=%d, UAVSal.forward_clips, prec=%s, %s" % (
+            H, W, C, T, args.prec, "hipGraph replay" if args.graph else "launch loop"),
+            "clips_per_gpu": C, "seq_len": T, "height": H, "width": W, "precision": args.prec,
+            "parallelism": "clip-sharded x%d, one all-gather of maps per step" % world if distributed else "single GPU"},
+    }
+
+    if rank == 0 and world == 1:
+        eng = model._engine(device, C, T, H, W, "clip", False, torch.float32)
+        if not args.no_roofline:
+            groups = kernel_rooflines(eng, args.prec)
+            tot = sum(g["ms"] for g in groups.values())
+            dom = max(groups.items(), key=lambda kv: kv[1]["ms"])
+            result["roofline"] = roofline_obj(dom[0], dom[1], args.prec)
+            result["roofline"]["share_of_kernel_time"] = round(dom[1]["ms"] / tot, 3)
+            if "dw" in groups:
+                result["roofline_dw"] = roofline_obj("dw3x3_kernel", groups["dw"], args.prec)
+                result["roofline_dw"]["share_of_kernel_time"] = round(groups["dw"]["ms"] / tot, 3)
+            result["kernel_time_ms"] = {k: round(v["ms"], 4) for k, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])}
+            result["stage_time_ms"] = {k: round(eng.time_ops(a, b, 5), 4) for k, (a, b) in eng.stage_ranges.items()}
+        if not args.no_cpu_baseline:
+            from oracle.uavsal_ref import build_oracle       # checker / baseline only
+            cores = os.cpu_count() or 1
+            torch.set_num_threads(cores)
+            oracle = build_oracle(time_dims=T, seed=0)
+            xc, cbc = x_cpu[:1], [cb_cpu[0][:1], cb_cpu[1][:1]]
+            oracle.forward_clips(xc, cbc)                    # warm-up
+            best = 1e30
+            for _ in range(3):
+                t0 = time.perf_counter()
+                ref_out, ref_state = oracle.forward_clips(xc, cbc)
+                best = min(best, time.perf_counter() - t0)
+            result["cpu_baseline"] = {"value": round(T / best, 3), "unit": "frames/s", "cores": torch.get_num_threads(),
+                                      "kind": "port", "sample": "1 clip x %d frames at %dx%d, best of 3 after 1 warm-up, "
+                                      "torch-CPU fp32 oracle (oracle/uavsal_ref.py)" % (T, H, W)}
+            err = (last["out"][:1].cpu() - ref_out).abs().max().item()
+            serr = (last["state"][:1].cpu() - ref_state).abs().max().item()
+            result["parity"] = {"max_abs_map_vs_cpu_ref": float("%.3e" % err), "max_abs_state_vs_cpu_ref": float("%.3e" % serr),
+                                "tolerance": 1e-3}
+        if not args.no_extra and (C, args.prec) != (8, "f16x3"):
+            try:
+                m2 = UAVSal(time_dims=T, precision="f16x3")
+                synth.load_synth_weights(m2, 0)
+                m2 = m2.to(device).eval()
+                m2.use_graph = True
+                x8, cb8 = make_clips(8, T, H, W)
+                x8 = x8.to(device)
+                cb8 = [cb8[0].to(device), cb8[1].to(device)]
+                dt8 = timed_steps(lambda: m2.forward_clips(x8, cb8, None), max(5, args.steps // 2), 2, False, device)
+                result["extra"] = {"workload": "%dx%d batch=8 seq=%d, prec=f16x3 (3x f16 split MFMA), hipGraph" % (H, W, T),
+                                   "value": round(8 * T * max(5, args.steps // 2) / dt8, 2), "unit": "frames/s"}
+            except Exception as e:  # extra is informative only
+                result["extra"] = {"error": repr(e)[:200]}
+
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -74,6 +74,7 @@ DESC_TYPES = [ConvDesc, DwDesc, StemDesc, BilinearDesc, TdiffDesc, TsumDesc, Lay
 # every symbol include/uavsal_hip.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("uavsal_conv_gemm", C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    ("uavsal_conv_tile", C.c_int, [C.POINTER(ConvDesc)]),
     ("uavsal_dw3x3", C.c_int, [C.POINTER(DwDesc), C.c_void_p]),
     ("uavsal_stem_conv", C.c_int, [C.POINTER(StemDesc), C.c_void_p]),
     ("uavsal_bilinear_ac", C.c_int, [C.POINTER(BilinearDesc), C.c_void_p]),

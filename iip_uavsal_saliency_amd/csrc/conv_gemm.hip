@@ -388,6 +388,12 @@ int pick_tile(long long M, int Cout) {
 
 }  // namespace
 
+extern "C" int uavsal_conv_tile(const uavsal_conv_desc* d) {
+    if (!d || d->n_img <= 0 || d->H <= 0 || d->W <= 0 || d->Cout <= 0) return UAVSAL_EINVAL;
+    if (d->tile >= 1 && d->tile <= 4) return d->tile;
+    return pick_tile((long long)d->H * d->W * d->n_img, d->Cout);
+}
+
 extern "C" int uavsal_conv_gemm(const uavsal_conv_desc* d, uavsal_stream_t stream) {
     if (!d || !d->a || !d->w || !d->out) return UAVSAL_EINVAL;
     if (d->n_img <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0) return UAVSAL_EINVAL;

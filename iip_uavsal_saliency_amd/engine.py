@@ -182,6 +182,7 @@ class Engine:
         d.n_img, d.H, d.W = n_img, a.h, a.w
         d.Cin, d.Cout, d.taps = cin, cout, taps
         d.prec, d.act, d.epi, d.tile = self.prec, act, epi, 0
+        self.ops_meta[-1]["tile"] = int(self.lib.uavsal_conv_tile(C.byref(d)))
         self._add(self.lib.uavsal_plan_add_conv, d, "plan_add_conv(%s)" % name)
 
     def dw(self, name, a: V, conv, bn, out: V, stride, dilation):

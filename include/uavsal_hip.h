@@ -103,6 +103,8 @@ typedef struct uavsal_conv_desc {
 } uavsal_conv_desc;
 
 int uavsal_conv_gemm(const uavsal_conv_desc* d, uavsal_stream_t stream);
+/* block tile `uavsal_conv_gemm` will use for this descriptor (1..4, see `tile`); no launch */
+int uavsal_conv_tile(const uavsal_conv_desc* d);
 
 /*
  * Depthwise 3x3 convolution + folded BatchNorm + ReLU6, NHWC, stride 1 or 2,

@@ -1,0 +1,206 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol the header
+declares, the host packing is what the kernels document, the drop-in module tree has the
+reference's schema, errors surface as in the reference, and the clip sharding / all-gather
+layer is correct for world_size 2 over gloo."""
+import os
+import re
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from iip_uavsal_saliency_amd import packing as P
+from iip_uavsal_saliency_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from iip_uavsal_saliency_amd import build, _lib
+    build.build()                      # hipcc cross-compiles gfx950 without a GPU
+    return _lib.load()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, "include", "uavsal_hip.h")).read()
+    declared = set(re.findall(r"\b(uavsal_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"uavsal_plan"}        # the opaque type
+    assert len(declared) >= 24
+    from iip_uavsal_saliency_amd import _lib
+    bound = {s[0] for s in _lib.SYMBOLS}
+    assert declared == bound, (declared ^ bound)
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.uavsal_abi_version() == 1
+    assert b"gfx950" in lib.uavsal_build_info()
+
+
+def test_argument_validation_without_gpu(lib):
+    """Rejected descriptors return before any HIP call, so this runs without a device."""
+    import ctypes as C
+    from iip_uavsal_saliency_amd import _lib as L
+    d = L.ConvDesc()
+    assert lib.uavsal_conv_gemm(C.byref(d), None) == -1            # null pointers
+    d.a, d.w, d.out = 16, 16, 16
+    d.n_img, d.H, d.W, d.Cin, d.Cout, d.taps, d.lda, d.ldc = 1, 4, 4, 6, 8, 1, 6, 8
+    d.a_img_stride = d.o_img_stride = 16
+    assert lib.uavsal_conv_gemm(C.byref(d), None) == -2            # Cin % 4
+    d.Cin, d.lda, d.taps = 16, 16, 9
+    assert lib.uavsal_conv_gemm(C.byref(d), None) == -3            # 3x3 needs Cin % 32
+    t = L.TdiffDesc()
+    t.inp, t.out, t.n_img, t.HW, t.C, t.seq_len, t.ldi, t.ldo = 16, 16, 1, 4, 32, 1, 32, 64
+    assert lib.uavsal_tdiff(C.byref(t), None) == -3                # one frame per sequence
+    p = lib.uavsal_plan_create()
+    assert lib.uavsal_plan_size(p) == 0
+    assert lib.uavsal_plan_graph_launch(p, None) == -4             # no graph built yet
+    lib.uavsal_plan_destroy(p)
+
+
+def test_fold_bn_matches_batch_norm():
+    bn = torch.nn.BatchNorm2d(24).eval()
+    g = torch.Generator().manual_seed(0)
+    bn.weight.data = torch.rand(24, generator=g) + 0.5
+    bn.bias.data = torch.rand(24, generator=g) - 0.5
+    bn.running_mean.data = torch.rand(24, generator=g) - 0.5
+    bn.running_var.data = torch.rand(24, generator=g) + 0.1
+    x = torch.rand((2, 24, 5, 5), generator=g) * 4 - 2
+    s, b = P.fold_bn(bn)
+    assert torch.allclose(x * s.view(1, -1, 1, 1) + b.view(1, -1, 1, 1), bn(x), atol=1e-6)
+
+
+@pytest.mark.parametrize("shape", [(24, 20, 1, 1), (1, 1536, 1, 1), (40, 64, 3, 3)])
+def test_pack_conv_weight_layouts(shape):
+    g = torch.Generator().manual_seed(1)
+    w = torch.rand(shape, generator=g) - 0.5
+    cout, cin, kh, _ = shape
+    k = cin * kh * kh
+    ref = w.permute(0, 2, 3, 1).reshape(cout, k)                 # k = tap*Cin + ci
+    f = P.pack_conv_weight(w, "f32").view(torch.float32)
+    npad, kpad = P.roundup(cout, 32), P.roundup(k, 16)
+    f = f.view(npad, kpad)
+    assert torch.equal(f[:cout, :k], ref) and f[cout:].abs().sum() == 0 and f[:, k:].abs().sum() == 0
+    kpad = P.roundup(k, 32)
+    inv = torch.empty(32, dtype=torch.long)
+    inv[torch.tensor(P._K_PERM32)] = torch.arange(32)
+    for prec, dt, scale, tol in (("bf16x3", torch.bfloat16, 1.0, 2.0 ** -15), ("f16x3", torch.float16, 64.0, 2.0 ** -20)):
+        hl = P.pack_conv_weight(w, prec).view(dt).view(2, npad, kpad).float()
+        rec = (hl[0] + hl[1]).view(npad, kpad // 32, 32)[:, :, inv].reshape(npad, kpad) / scale
+        assert (rec[:cout, :k] - ref).abs().max().item() <= tol * ref.abs().max().item()
+    h1 = P.pack_conv_weight(w, "bf16").view(torch.bfloat16).view(npad, kpad)
+    assert torch.equal(h1, P.pack_conv_weight(w, "bf16x3").view(torch.bfloat16).view(2, npad, kpad)[0])
+
+
+def test_pack_dw_and_stem():
+    w = torch.arange(4 * 9, dtype=torch.float32).view(4, 1, 3, 3)
+    p = P.pack_dw_weight(w)
+    assert p.shape == (9, 4) and p[5, 2] == w[2, 0, 1, 2]
+    ws = torch.arange(32 * 27, dtype=torch.float32).view(32, 3, 3, 3)
+    s = P.pack_stem_weight(ws)
+    assert s.shape == (27, 32) and s[1 * 9 + 2 * 3 + 1, 7] == ws[7, 1, 2, 1]
+
+
+def test_dropin_schema_matches_reference():
+    """Same keys/shapes as the oracle tree (itself pinned to the reference's 51.59 MB known
+    answer, Tools/Getmodelsize_demo.py:93) and the attribute names that tool touches (:52-82)."""
+    from iip_uavsal_saliency_amd import UAVSal
+    from oracle.uavsal_ref import RefUAVSal
+    m, r = UAVSal(), RefUAVSal()
+    sd, rd = m.state_dict(), r.state_dict()
+    assert list(sd.keys()) == list(rd.keys()) and len(sd) == 685
+    assert all(sd[k].shape == rd[k].shape for k in sd)
+    assert sum(p.numel() for p in m.parameters()) == 13407338
+    for attr in ("sfnet", "st_layer", "fust_layer", "gauss_cb_layer", "ob_cb_layer", "cxt_cb_prior",
+                 "fucb_layer", "fucbst_layer", "rnn", "conv_out_st", "time_dims", "num_stblock", "num_cb"):
+        assert hasattr(m, attr)
+    assert m.rnn.cell_list[0].rnn_conv.weight.shape == (256, 512, 3, 3)
+    m.load_state_dict(r.state_dict())          # weights interchange with the reference schema
+
+
+def test_no_cpu_fallback():
+    from iip_uavsal_saliency_amd import UAVSal
+    m = UAVSal(time_dims=2).eval()
+    x = torch.zeros(2, 3, 72, 104)
+    cb = [torch.zeros(2, 8, 9, 13), torch.zeros(2, 20, 9, 13)]
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(x, cb, None)
+    with pytest.raises(RuntimeError):
+        m.sfnet(x)                              # sub-modules hold parameters only
+    m.train()
+    with pytest.raises(RuntimeError, match="inference-only"):
+        m(x, cb, None)
+
+
+def test_synth_is_deterministic():
+    a = synth.synth_tensor("sfnet.conv_last.0.weight", (256, 448, 3, 3))
+    b = synth.synth_tensor("sfnet.conv_last.0.weight", (256, 448, 3, 3))
+    assert np.array_equal(a, b) and abs(float(a.std()) - np.sqrt(2.0 / (448 * 9))) < 1e-3
+    f = synth.synth_frames_u8(3, 24, 40)
+    assert f.dtype == np.uint8 and f.shape == (3, 3, 24, 40) and not np.array_equal(f[0], f[1])
+    g = synth.gauss_priors(2, 45, 80)
+    assert g.shape == (2, 8, 45, 80) and g.min() >= 0 and g.max() <= 1.0
+
+
+def test_clip_shard_partition():
+    from iip_uavsal_saliency_amd.parallel import ClipShard
+    seen = []
+    for r in range(8):
+        s = ClipShard(64, 8, r)
+        seen += list(range(s.first, s.first + s.count))
+    assert seen == list(range(64))
+    with pytest.raises(ValueError):
+        ClipShard(10, 4, 0)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from iip_uavsal_saliency_amd.parallel import forward_clips_sharded
+    from oracle.uavsal_ref import build_oracle
+    model = build_oracle(time_dims=2)          # any module with forward_clips; the oracle runs on CPU
+    C, T, H, W = 2, 2, 72, 104
+    x = torch.from_numpy(synth.normalize_frames(synth.synth_frames_u8(C * T, H, W))).view(C, T, 3, H, W)
+    cb = [torch.from_numpy(synth.gauss_priors(C * T, 9, 13)).view(C, T, 8, 9, 13),
+          torch.from_numpy(synth.ob_priors(C * T, 9, 13)).view(C, T, 20, 9, 13)]
+    out, st = forward_clips_sharded(model, x, cb)
+    q.put((rank, out.numpy(), st.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_forward_equals_single_process_gloo_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict()
+    for _ in range(2):
+        r, out, st = q.get(timeout=240)
+        got[r] = (out, st)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from oracle.uavsal_ref import build_oracle
+    model = build_oracle(time_dims=2)
+    C, T, H, W = 2, 2, 72, 104
+    x = torch.from_numpy(synth.normalize_frames(synth.synth_frames_u8(C * T, H, W))).view(C, T, 3, H, W)
+    cb = [torch.from_numpy(synth.gauss_priors(C * T, 9, 13)).view(C, T, 8, 9, 13),
+          torch.from_numpy(synth.ob_priors(C * T, 9, 13)).view(C, T, 20, 9, 13)]
+    ref_out, ref_st = model.forward_clips(x, cb)
+    for r in range(2):
+        assert np.allclose(got[r][0], ref_out.numpy(), atol=1e-6)     # every rank holds all maps
+        assert np.allclose(got[r][1], ref_st[r:r + 1].numpy(), atol=1e-6)   # states stay local
+    assert np.array_equal(got[0][0], got[1][0])
