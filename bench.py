@@ -39,6 +39,24 @@ DTYPE_NAME = {"f32": "f32", "f16x3": "f32 (3x f16 split MFMA, f32 accumulate)",
 TILE_NAME = {1: "128x128", 2: "128x64", 3: "128x32", 4: "64x64"}
 
 
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench %.1fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
+
+
+def host_cores():
+    """CPU share of this process (the GPU box gives a 1-GPU job 16 cores; os.cpu_count() would
+    report the whole host and oversubscribe oneDNN)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
 def make_clips(C, T, H, W, seed=0):
     from iip_uavsal_saliency_amd import synth
     h, w = H // 8, W // 8
@@ -157,7 +175,9 @@ def main():
             gather_maps(out, gathered)
         last["out"], last["state"] = out, st
 
+    log("model + inputs ready; timing %d steps" % args.steps)
     dt = timed_steps(step, args.steps, args.warmup, distributed, device)
+    log("timed region done: %.3f ms/step" % (dt / args.steps * 1e3))
     frames = C * T * world * args.steps
     fps = frames / dt
     result = {
@@ -174,6 +194,7 @@ def main():
     if rank == 0 and world == 1:
         eng = model._engine(device, C, T, H, W, "clip", False, torch.float32)
         if not args.no_roofline:
+            log("per-kernel hipEvent timing of %d launches" % len(eng.ops_meta))
             groups = kernel_rooflines(eng, args.prec)
             tot = sum(g["ms"] for g in groups.values())
             dom = max(groups.items(), key=lambda kv: kv[1]["ms"])
@@ -186,8 +207,9 @@ def main():
             result["stage_time_ms"] = {k: round(eng.time_ops(a, b, 5), 4) for k, (a, b) in eng.stage_ranges.items()}
         if not args.no_cpu_baseline:
             from oracle.uavsal_ref import build_oracle       # checker / baseline only
-            cores = os.cpu_count() or 1
+            cores = host_cores()
             torch.set_num_threads(cores)
+            log("cpu baseline: oracle on %d host threads" % cores)
             oracle = build_oracle(time_dims=T, seed=0)
             xc, cbc = x_cpu[:1], [cb_cpu[0][:1], cb_cpu[1][:1]]
             oracle.forward_clips(xc, cbc)                    # warm-up
@@ -196,6 +218,7 @@ def main():
                 t0 = time.perf_counter()
                 ref_out, ref_state = oracle.forward_clips(xc, cbc)
                 best = min(best, time.perf_counter() - t0)
+                log("cpu baseline pass: %.2f s" % best)
             result["cpu_baseline"] = {"value": round(T / best, 3), "unit": "frames/s", "cores": torch.get_num_threads(),
                                       "kind": "port", "sample": "1 clip x %d frames at %dx%d, best of 3 after 1 warm-up, "
                                       "torch-CPU fp32 oracle (oracle/uavsal_ref.py)" % (T, H, W)}
@@ -204,6 +227,7 @@ def main():
             result["parity"] = {"max_abs_map_vs_cpu_ref": float("%.3e" % err), "max_abs_state_vs_cpu_ref": float("%.3e" % serr),
                                 "tolerance": 1e-3}
         if not args.no_extra and (C, args.prec) != (8, "f16x3"):
+            log("extra: 8 clips, f16x3, hipGraph")
             try:
                 m2 = UAVSal(time_dims=T, precision="f16x3")
                 synth.load_synth_weights(m2, 0)

@@ -93,7 +93,7 @@ __device__ __forceinline__ f32x4 prescale(f32x4 x) {
 }
 
 template <int PREC, int WAVES_M, int WAVES_N, int WM, int WN, int TAPS>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvK p) {
+__global__ __launch_bounds__(256, (WM * WN >= 4) ? 3 : 4) void conv_gemm_kernel(const ConvK p) {
     constexpr int BM = WAVES_M * WM * 32;
     constexpr int BN = WAVES_N * WN * 32;
     constexpr int KT = (PREC == UAVSAL_PREC_F32) ? 16 : 32;
@@ -110,33 +110,47 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvK p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
-    const int v = xcd_virtual_block(blockIdx.x, p.nblk);
-    const int tile_m = v / p.tiles_n;
-    const int tile_n = v - tile_m * p.tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    // Persistent workgroups: the grid is sized to the resident capacity of the chip and every
+    // workgroup walks a contiguous range of output tiles (N fastest, so consecutive tiles
+    // re-read the same activation rows from L1/L2).  The virtual block id keeps each XCD on
+    // one contiguous range of tiles.  The first K tile of the NEXT output tile is requested
+    // before the epilogue of the current one, which hides the prologue's HBM/L2 latency --
+    // with K as short as 256 (16 K tiles) that latency was a third of the kernel's time.
+    const int G = gridDim.x;
+    const int vb = xcd_virtual_block(blockIdx.x, G);
+    int tile = (int)(((long long)vb * p.nblk) / G);
+    const int tile_end = (int)(((long long)(vb + 1) * p.nblk) / G);
+    if (tile >= tile_end) return;
+    int m0 = 0, n0 = 0;
 
     // ---- per-thread staging coordinates ------------------------------------------------
     const int ch = tid & 3;              // 16-byte chunk within the 64-byte panel row
     long long a_base[A_IT];
     int a_y[A_IT], a_x[A_IT];
     bool a_ok[A_IT];
+    auto setup_tile = [&](int t) {
+        const int tile_m = t / p.tiles_n;
+        const int tile_n = t - tile_m * p.tiles_n;
+        m0 = tile_m * BM;
+        n0 = tile_n * BN;
 #pragma unroll
-    for (int it = 0; it < A_IT; ++it) {
-        const int row = (tid >> 2) + it * 64;
-        const int m = m0 + row;
-        a_ok[it] = m < p.M;
-        const int mm = a_ok[it] ? m : 0;
-        if (TAPS == 1) {
-            a_base[it] = row_off(mm, p.HW, p.a_is, p.contig) * p.lda;
-            a_y[it] = 0; a_x[it] = 0;
-        } else {
-            const int img = mm / p.HW;
-            const int pix = mm - img * p.HW;
-            a_y[it] = pix / p.W;
-            a_x[it] = pix - a_y[it] * p.W;
-            a_base[it] = (long long)img * p.a_is;   // in pixels; tap offset added per tile
+        for (int it = 0; it < A_IT; ++it) {
+            const int row = (tid >> 2) + it * 64;
+            const int m = m0 + row;
+            a_ok[it] = m < p.M;
+            const int mm = a_ok[it] ? m : 0;
+            if (TAPS == 1) {
+                a_base[it] = row_off(mm, p.HW, p.a_is, p.contig) * p.lda;
+                a_y[it] = 0; a_x[it] = 0;
+            } else {
+                const int img = mm / p.HW;
+                const int pix = mm - img * p.HW;
+                a_y[it] = pix / p.W;
+                a_x[it] = pix - a_y[it] * p.W;
+                a_base[it] = (long long)img * p.a_is;   // in pixels; tap offset added per tile
+            }
         }
-    }
+    };
     const int b_row0 = tid >> 2;
 
     f32x4 a_reg[A_IT][NLD];
@@ -225,14 +239,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvK p) {
         }
     };
 
-    // ---- accumulators ----------------------------------------------------------------
     f32x16 acc[WM][WN];
-#pragma unroll
-    for (int i = 0; i < WM; ++i)
-#pragma unroll
-        for (int j = 0; j < WN; ++j)
-#pragma unroll
-            for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
 
     const int wave = tid >> 6, lane = tid & 63;
     const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
@@ -295,54 +302,92 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvK p) {
         }
     };
 
-    // ---- main loop ---------------------------------------------------------------------
+    // ---- persistent loop over this workgroup's output tiles -------------------------------
+    setup_tile(tile);
     load_tile(0);
-    store_tile(0);
-    __syncthreads();
-    for (int kt = 0; kt < p.ktiles; ++kt) {
-        const int cur = kt & 1;
-        const bool more = (kt + 1) < p.ktiles;
-        if (more) load_tile(kt + 1);
-        compute(cur);
-        if (more) store_tile(cur ^ 1);
-        __syncthreads();
-    }
+    while (true) {
+        const int m0c = m0, n0c = n0;          // coordinates of the tile being computed
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
 
-    // ---- epilogue ----------------------------------------------------------------------
+        store_tile(0);
+        __syncthreads();
+        for (int kt = 0; kt < p.ktiles; ++kt) {
+            const int cur = kt & 1;
+            const bool more = (kt + 1) < p.ktiles;
+            if (more) load_tile(kt + 1);
+            compute(cur);
+            if (more) store_tile(cur ^ 1);
+            __syncthreads();
+        }
+
+        // request the next tile's first K tile now; it lands while the epilogue runs
+        const bool has_next = (tile + 1) < tile_end;
+        if (has_next) {
+            ++tile;
+            setup_tile(tile);
+            load_tile(0);
+        }
+
+        // ---- epilogue ------------------------------------------------------------------
+        float sc[WN], bi[WN];
 #pragma unroll
-    for (int i = 0; i < WM; ++i) {
+        for (int j = 0; j < WN; ++j) {
+            const int n = n0c + (wn * WN + j) * 32 + lr;
+            const bool okn = (p.scale != nullptr) && n < p.Cout;
+            sc[j] = okn ? p.scale[n] : 1.f;
+            bi[j] = okn ? p.bias[n] : 0.f;
+        }
 #pragma unroll
-        for (int g = 0; g < 16; ++g) {
-            const int m = m0 + (wm * WM + i) * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
-            if (m >= p.M) continue;
-            const long long oo = row_off(m, p.HW, p.o_is, p.contig) * p.ldc;
-            long long ro = 0, xo = 0, ao = 0;
-            if (p.res) ro = row_off(m, p.HW, p.r_is, p.contig) * p.ldr;
-            if (p.epi == UAVSAL_EPI_TWA) {
-                xo = row_off(m, p.HW, p.x_is, p.contig) * p.ldx;
-                ao = row_off(m, p.HW, p.a_is, p.contig) * p.lda;
-            }
+        for (int i = 0; i < WM; ++i) {
 #pragma unroll
-            for (int j = 0; j < WN; ++j) {
-                const int n = n0 + (wn * WN + j) * 32 + lr;
-                if (n >= p.Cout) continue;
-                float vv = acc[i][j][g];
-                if (PREC == UAVSAL_PREC_F16X3) vv *= F16X3_ACC_SCALE;
+            for (int g = 0; g < 16; ++g) {
+                const int m = m0c + (wm * WM + i) * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
+                if (m >= p.M) continue;
+                const long long oo = row_off(m, p.HW, p.o_is, p.contig) * p.ldc;
+                long long ro = 0, xo = 0, ao = 0;
+                if (p.res) ro = row_off(m, p.HW, p.r_is, p.contig) * p.ldr;
                 if (p.epi == UAVSAL_EPI_TWA) {
-                    const float z = vv + p.aux[xo + n];
-                    const float gate = 1.f / (1.f + expf(-z));
-                    const float xt = p.res[ro + n];
-                    const float hp = p.a[ao + n];
-                    vv = gate * xt + (1.f - gate) * hp;
-                } else {
-                    if (p.scale) vv = vv * p.scale[n] + p.bias[n];
-                    vv = apply_act(vv, p.act);
-                    if (p.res) vv += p.res[ro + n];
+                    xo = row_off(m, p.HW, p.x_is, p.contig) * p.ldx;
+                    ao = row_off(m, p.HW, p.a_is, p.contig) * p.lda;
                 }
-                p.out[oo + n] = vv;
+#pragma unroll
+                for (int j = 0; j < WN; ++j) {
+                    const int n = n0c + (wn * WN + j) * 32 + lr;
+                    if (n >= p.Cout) continue;
+                    float vv = acc[i][j][g];
+                    if (PREC == UAVSAL_PREC_F16X3) vv *= F16X3_ACC_SCALE;
+                    if (p.epi == UAVSAL_EPI_TWA) {
+                        const float z = vv + p.aux[xo + n];
+                        const float gate = 1.f / (1.f + expf(-z));
+                        const float xt = p.res[ro + n];
+                        const float hp = p.a[ao + n];
+                        vv = gate * xt + (1.f - gate) * hp;
+                    } else {
+                        vv = vv * sc[j] + bi[j];
+                        vv = apply_act(vv, p.act);
+                        if (p.res) vv += p.res[ro + n];
+                    }
+                    p.out[oo + n] = vv;
+                }
             }
         }
+        if (!has_next) break;
     }
+}
+
+// resident workgroups per CU for one kernel instantiation (cached; queried once, outside any capture)
+template <typename K>
+int resident_grid(K kernel, int smem) {
+    int per_cu = 0, cus = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, smem) != hipSuccess || per_cu <= 0) per_cu = 1;
+    return per_cu * cus;
 }
 
 template <int PREC, int WAVES_M, int WAVES_N, int WM, int WN>
@@ -354,10 +399,15 @@ int launch_variant(const ConvK& k0, int taps, hipStream_t stream) {
     const int tiles_m = (k.M + BM - 1) / BM;
     k.tiles_n = (k.Cout + BN - 1) / BN;
     k.nblk = tiles_m * k.tiles_n;
-    if (taps == 1)
-        hipLaunchKernelGGL((conv_gemm_kernel<PREC, WAVES_M, WAVES_N, WM, WN, 1>), dim3(k.nblk), dim3(256), SMEM, stream, k);
-    else
-        hipLaunchKernelGGL((conv_gemm_kernel<PREC, WAVES_M, WAVES_N, WM, WN, 9>), dim3(k.nblk), dim3(256), SMEM, stream, k);
+    if (taps == 1) {
+        static const int cap = resident_grid(conv_gemm_kernel<PREC, WAVES_M, WAVES_N, WM, WN, 1>, SMEM);
+        const int grid = k.nblk < cap ? k.nblk : cap;
+        hipLaunchKernelGGL((conv_gemm_kernel<PREC, WAVES_M, WAVES_N, WM, WN, 1>), dim3(grid), dim3(256), SMEM, stream, k);
+    } else {
+        static const int cap = resident_grid(conv_gemm_kernel<PREC, WAVES_M, WAVES_N, WM, WN, 9>, SMEM);
+        const int grid = k.nblk < cap ? k.nblk : cap;
+        hipLaunchKernelGGL((conv_gemm_kernel<PREC, WAVES_M, WAVES_N, WM, WN, 9>), dim3(grid), dim3(256), SMEM, stream, k);
+    }
     return uavsal_launch_status();
 }
 

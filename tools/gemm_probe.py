@@ -1,0 +1,52 @@
+"""Times uavsal_conv_gemm on chosen shapes (hipEvents on the launch stream) -- tuning aid."""
+import ctypes as C
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from iip_uavsal_saliency_amd import _lib as L, packing as P
+
+lib = L.load()
+dev = torch.device("cuda")
+
+
+def run(M_hw, n_img, cin, cout, taps, prec, tile, iters=20, act=1, scale=True):
+    h, w = M_hw
+    a = torch.rand((n_img * h * w, cin), device=dev) * 2 - 1
+    wt = (torch.rand((cout, cin, 3 if taps == 9 else 1, 3 if taps == 9 else 1)) - 0.5) * 0.1
+    wp = P.pack_conv_weight(wt, prec).to(dev)
+    out = torch.empty((n_img * h * w, cout), device=dev)
+    s = torch.ones(P.roundup(cout, 32), device=dev)
+    b = torch.zeros(P.roundup(cout, 32), device=dev)
+    d = L.ConvDesc()
+    d.a, d.lda, d.a_img_stride = a.data_ptr(), cin, h * w
+    d.w = wp.data_ptr()
+    if scale:
+        d.scale, d.bias = s.data_ptr(), b.data_ptr()
+    d.out, d.ldc, d.o_img_stride = out.data_ptr(), cout, h * w
+    d.n_img, d.H, d.W, d.Cin, d.Cout, d.taps = n_img, h, w, cin, cout, taps
+    d.prec, d.act, d.epi, d.tile = L.PREC[prec], act, 0, tile
+    plan = C.c_void_p(lib.uavsal_plan_create())
+    lib.uavsal_plan_add_conv(plan, C.byref(d))
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ms = C.c_float()
+    lib.uavsal_plan_time(plan, 0, 1, 3, st, C.byref(ms))
+    L.check(lib.uavsal_plan_time(plan, 0, 1, iters, st, C.byref(ms)), "time")
+    lib.uavsal_plan_destroy(plan)
+    fl = 2.0 * n_img * h * w * cin * cout * taps
+    return ms.value, fl / ms.value / 1e9
+
+
+if __name__ == "__main__":
+    shapes = [((45, 80), 8, 256, 1536, 1), ((45, 80), 8, 1536, 256, 1), ((45, 80), 8, 4096, 1536, 1),
+              ((45, 80), 8, 256, 256, 1), ((45, 80), 8, 448, 256, 9), ((45, 80), 1, 256, 256, 9),
+              ((180, 320), 8, 16, 96, 1), ((180, 320), 8, 96, 24, 1), ((45, 80), 64, 256, 1536, 1)]
+    precs = sys.argv[1].split(",") if len(sys.argv) > 1 else ["f32", "f16x3"]
+    for prec in precs:
+        for sh in shapes:
+            for tile in (1, 2, 4):
+                if sh[3] < 64 and tile != 1:
+                    continue
+                t = 3 if sh[3] <= 32 else tile
+                ms, tf = run(*sh, prec, t)
+                print("%-6s hw=%s n=%d K=%d N=%d taps=%d tile=%d : %8.1f us  %7.2f TFLOP/s" % (
+                    prec, sh[0], sh[1], sh[2], sh[3], sh[4], t, ms * 1e3, tf), flush=True)
