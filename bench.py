@@ -77,6 +77,9 @@ def kernel_rooflines(eng, prec, iters=5):
             key = "conv_gemm_kernel<%s,%s,taps=%d>" % (prec, TILE_NAME[m["tile"]], 9 if m["kind"] == "conv3" else 1)
         else:
             key = m["kind"]
+        if os.environ.get("UAVSAL_BENCH_OPS"):
+            print("[op %3d] %-28s %-8s %9.1f us %8.1f GB/s %8.2f TFLOP/s" % (
+                i, m["name"], key[-22:], ms * 1e3, m["bytes"] / ms / 1e6, m["flops"] / ms / 1e9), file=sys.stderr)
         g = groups.setdefault(key, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0, "kind": m["kind"]})
         g["ms"] += ms
         g["flops"] += m["flops"]

@@ -92,8 +92,94 @@ __device__ __forceinline__ f32x4 prescale(f32x4 x) {
     return x;
 }
 
+// ---- epilogue ---------------------------------------------------------------------------
+// The accumulators leave through one of two paths.  The fast path covers every launch but the
+// ConvTWA step and the final sigmoid: dense images (img stride == H*W), act in {none, ReLU6}.
+// Its per-element cost is what bounds the short-K layers (K = 16..256: the epilogue used to
+// take as long as the MFMAs), so it is kept to: fma, v_med3 clamp, optional residual load+add,
+// one store with a wave-uniform base + 32-bit lane offset.  Written as a macro expanded inside
+// each kernel: handing the accumulator array to a function demotes it to scratch memory.
+#define UAVSAL_GEMM_EPILOGUE(ACC_SCALE, STG)                                                         \
+    {                                                                                                \
+        const bool fast_ = p.contig && p.epi == UAVSAL_EPI_AFFINE && p.act != UAVSAL_ACT_SIGMOID;    \
+        const bool vec_ = fast_ && !(p.ldc & 3) && !(p.Cout & 3) && !((size_t)p.out & 15) &&         \
+                          (!p.res || (!(p.ldr & 3) && !((size_t)p.res & 15)));                       \
+        float sc[WN], bi[WN];                                                                        \
+        int col[WN];                                                                                 \
+        bool cok[WN];                                                                                \
+        _Pragma("unroll") for (int j = 0; j < WN; ++j) {                                             \
+            col[j] = (wn * WN + j) * 32 + lr;                                                        \
+            cok[j] = n0c + col[j] < p.Cout;                                                          \
+            const bool okn = (p.scale != nullptr) && cok[j];                                         \
+            sc[j] = (okn ? p.scale[n0c + col[j]] : 1.f) * (ACC_SCALE);                               \
+            bi[j] = okn ? p.bias[n0c + col[j]] : 0.f;                                                \
+        }                                                                                            \
+        if (vec_) {                                                                                  \
+            /* 32-row blocks go through LDS so that every lane stores 16 B and a wave covers whole  \
+               rows: 4x fewer store instructions (the store queue, not HBM, bounds short-K layers) */ \
+            const float lo = p.act == UAVSAL_ACT_RELU6 ? 0.f : -3.0e38f;                             \
+            const float hi = p.act == UAVSAL_ACT_RELU6 ? 6.f : 3.0e38f;                              \
+            float* stg = reinterpret_cast<float*>(STG);                                              \
+            _Pragma("unroll") for (int pp = 0; pp < BM / 32; ++pp) {                                 \
+                _Pragma("unroll") for (int i = 0; i < WM; ++i) {                                     \
+                    if (wm * WM + i == pp) {                                                         \
+                        _Pragma("unroll") for (int g = 0; g < 16; ++g) {                             \
+                            const int r = (g & 3) + 8 * (g >> 2) + 4 * lh;                           \
+                            _Pragma("unroll") for (int j = 0; j < WN; ++j)                           \
+                                stg[r * BN + col[j]] =                                               \
+                                    __builtin_amdgcn_fmed3f(fmaf(acc[i][j][g], sc[j], bi[j]), lo, hi); \
+                        }                                                                            \
+                    }                                                                                \
+                }                                                                                    \
+                __syncthreads();                                                                     \
+                _Pragma("unroll") for (int it = 0; it < (32 * BN / 4 + 255) / 256; ++it) {           \
+                    const int idx = tid + it * 256;                                                  \
+                    const int row = idx / (BN / 4), c4 = idx - row * (BN / 4);                       \
+                    const int gm = m0c + pp * 32 + row, gn = n0c + c4 * 4;                           \
+                    if (row < 32 && gm < p.M && gn < p.Cout) {                                       \
+                        f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * BN + c4 * 4);          \
+                        if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (long long)gm * p.ldr + gn); \
+                        *reinterpret_cast<f32x4*>(p.out + (long long)gm * p.ldc + gn) = v;           \
+                    }                                                                                \
+                }                                                                                    \
+                __syncthreads();                                                                     \
+            }                                                                                        \
+        } else {                                                                                     \
+            _Pragma("unroll") for (int i = 0; i < WM; ++i) {                                         \
+                _Pragma("unroll") for (int g = 0; g < 16; ++g) {                                     \
+                    const int m = m0c + (wm * WM + i) * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;        \
+                    if (m >= p.M) continue;                                                          \
+                    const long long oo = row_off(m, p.HW, p.o_is, p.contig) * p.ldc;                 \
+                    long long ro = 0, xo = 0, ao = 0;                                                \
+                    if (p.res) ro = row_off(m, p.HW, p.r_is, p.contig) * p.ldr;                      \
+                    if (p.epi == UAVSAL_EPI_TWA) {                                                   \
+                        xo = row_off(m, p.HW, p.x_is, p.contig) * p.ldx;                             \
+                        ao = row_off(m, p.HW, p.a_is, p.contig) * p.lda;                             \
+                    }                                                                                \
+                    _Pragma("unroll") for (int j = 0; j < WN; ++j) {                                 \
+                        const int n = n0c + col[j];                                                  \
+                        if (!cok[j]) continue;                                                       \
+                        float vv;                                                                    \
+                        if (p.epi == UAVSAL_EPI_TWA) {                                               \
+                            const float z = acc[i][j][g] * (ACC_SCALE) + p.aux[xo + n];              \
+                            const float gate = 1.f / (1.f + expf(-z));                               \
+                            const float xt = p.res[ro + n];                                          \
+                            const float hp = p.a[ao + n];                                            \
+                            vv = gate * xt + (1.f - gate) * hp;                                      \
+                        } else {                                                                     \
+                            vv = apply_act(fmaf(acc[i][j][g], sc[j], bi[j]), p.act);                 \
+                            if (p.res) vv += p.res[ro + n];                                          \
+                        }                                                                            \
+                        p.out[oo + n] = vv;                                                          \
+                    }                                                                                \
+                }                                                                                    \
+            }                                                                                        \
+        }                                                                                            \
+    }
+
 template <int PREC, int WAVES_M, int WAVES_N, int WM, int WN, int TAPS>
-__global__ __launch_bounds__(256, (WM * WN >= 4) ? 3 : 4) void conv_gemm_kernel(const ConvK p) {
+__global__ __launch_bounds__(256, (WM * WN >= 4) ? ((PREC == UAVSAL_PREC_BF16X3 || PREC == UAVSAL_PREC_F16X3) ? 2 : 3) : 4)
+void conv_gemm_kernel(const ConvK p) {
     constexpr int BM = WAVES_M * WM * 32;
     constexpr int BN = WAVES_N * WN * 32;
     constexpr int KT = (PREC == UAVSAL_PREC_F32) ? 16 : 32;
@@ -334,48 +420,202 @@ __global__ __launch_bounds__(256, (WM * WN >= 4) ? 3 : 4) void conv_gemm_kernel(
         }
 
         // ---- epilogue ------------------------------------------------------------------
-        float sc[WN], bi[WN];
+        UAVSAL_GEMM_EPILOGUE((PREC == UAVSAL_PREC_F16X3 ? F16X3_ACC_SCALE : 1.0f), smem)
+        if (!has_next) break;
+    }
+}
+
+// =====================================================================================
+// fp32 path: LDS-DMA staged, multi-stage ring.
+//
+// fp32 operands need no conversion, so both tiles go global -> LDS directly
+// (global_load_lds_dwordx4: no VGPRs, no VALU, no ds_write) into a ring of S stages that is
+// kept D = S-1 K tiles ahead of the MFMAs.  One raw s_barrier per K tile:
+//   wait  : s_waitcnt vmcnt(LPT*(D-1))  -> this wave's DMA for tile kt has landed
+//   barrier: every wave's has (RAW), and every wave has finished reading the stage tile
+//            kt+D will overwrite (it was read in iteration kt-1)              (WAR)
+//   issue : DMA for tile kt+D
+//   compute tile kt from stage kt % S
+// The LDS destination of a DMA is wave-uniform base + lane*16, so the chunk swizzle is applied
+// on the per-lane SOURCE address (lane l of a 16-row group writes physical slot l&3 of row l>>2
+// and therefore fetches logical chunk (l&3) ^ ((row>>2)&3)); fragment reads use the same XOR.
+// Out-of-range lanes (M / K tails, 3x3 zero padding) fetch from a 16-byte zero page instead of
+// being masked off (a masked lane would leave stale LDS behind).
+__device__ __attribute__((aligned(16))) float g_zero16[4];
+
+template <int WAVES_M, int WAVES_N, int WM, int WN, int TAPS, int S>
+__global__ __launch_bounds__(256, (WM * WN >= 4) ? 3 : 4) void conv_gemm_f32_dma_kernel(const ConvK p) {
+    constexpr int BM = WAVES_M * WM * 32;
+    constexpr int BN = WAVES_N * WN * 32;
+    constexpr int KT = 16;
+    constexpr int A_IT = (BM * 4) / 256;
+    constexpr int B_IT = (BN * 4 + 255) / 256;
+    constexpr int LPT = A_IT + B_IT;             // DMA instructions per thread per K tile
+    constexpr int D = S - 1;                     // prefetch distance in K tiles
+    constexpr int APAN = BM * 64;
+    constexpr int BPAN = BN * 64;
+    constexpr int STAGE = APAN + BPAN;
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+    static_assert((BN * 4) % 256 == 0 || BN * 4 < 256, "B tile shape");
+    static_assert(LPT * (D - 1) < 64, "vmcnt immediate");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+
+    const int tid = threadIdx.x;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform
+    const int G = gridDim.x;
+    const int vb = xcd_virtual_block(blockIdx.x, G);
+    int tile = (int)(((long long)vb * p.nblk) / G);
+    const int tile_end = (int)(((long long)(vb + 1) * p.nblk) / G);
+    if (tile >= tile_end) return;
+    int m0 = 0, n0 = 0;
+
+    // per-thread DMA coordinates: row (tid>>2) + it*64 of the tile, physical chunk tid&3
+    const int pc = tid & 3;
+    long long a_base[A_IT];
+    int a_y[A_IT], a_x[A_IT], a_lc[A_IT];
+    bool a_ok[A_IT];
+    int b_lc[B_IT];
+    const float* zero = g_zero16;
+    auto setup_tile = [&](int t) {
+        const int tile_m = t / p.tiles_n;
+        const int tile_n = t - tile_m * p.tiles_n;
+        m0 = tile_m * BM;
+        n0 = tile_n * BN;
 #pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            const int n = n0c + (wn * WN + j) * 32 + lr;
-            const bool okn = (p.scale != nullptr) && n < p.Cout;
-            sc[j] = okn ? p.scale[n] : 1.f;
-            bi[j] = okn ? p.bias[n] : 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < WM; ++i) {
-#pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const int m = m0c + (wm * WM + i) * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
-                if (m >= p.M) continue;
-                const long long oo = row_off(m, p.HW, p.o_is, p.contig) * p.ldc;
-                long long ro = 0, xo = 0, ao = 0;
-                if (p.res) ro = row_off(m, p.HW, p.r_is, p.contig) * p.ldr;
-                if (p.epi == UAVSAL_EPI_TWA) {
-                    xo = row_off(m, p.HW, p.x_is, p.contig) * p.ldx;
-                    ao = row_off(m, p.HW, p.a_is, p.contig) * p.lda;
-                }
-#pragma unroll
-                for (int j = 0; j < WN; ++j) {
-                    const int n = n0c + (wn * WN + j) * 32 + lr;
-                    if (n >= p.Cout) continue;
-                    float vv = acc[i][j][g];
-                    if (PREC == UAVSAL_PREC_F16X3) vv *= F16X3_ACC_SCALE;
-                    if (p.epi == UAVSAL_EPI_TWA) {
-                        const float z = vv + p.aux[xo + n];
-                        const float gate = 1.f / (1.f + expf(-z));
-                        const float xt = p.res[ro + n];
-                        const float hp = p.a[ao + n];
-                        vv = gate * xt + (1.f - gate) * hp;
-                    } else {
-                        vv = vv * sc[j] + bi[j];
-                        vv = apply_act(vv, p.act);
-                        if (p.res) vv += p.res[ro + n];
-                    }
-                    p.out[oo + n] = vv;
-                }
+        for (int it = 0; it < A_IT; ++it) {
+            const int row = (tid >> 2) + it * 64;
+            a_lc[it] = pc ^ ((row >> 2) & 3);
+            const int m = m0 + row;
+            a_ok[it] = m < p.M;
+            const int mm = a_ok[it] ? m : 0;
+            if (TAPS == 1) {
+                a_base[it] = row_off(mm, p.HW, p.a_is, p.contig) * p.lda;
+                a_y[it] = 0; a_x[it] = 0;
+            } else {
+                const int img = mm / p.HW;
+                const int pix = mm - img * p.HW;
+                a_y[it] = pix / p.W;
+                a_x[it] = pix - a_y[it] * p.W;
+                a_base[it] = (long long)img * p.a_is;
             }
         }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            const int row = (tid >> 2) + it * 64;
+            b_lc[it] = pc ^ ((row >> 2) & 3);
+        }
+    };
+
+    auto issue_tile = [&](int kt, int stage) {
+        char* As = smem + stage * STAGE;
+        char* Bs = As + APAN;
+        int ci0 = kt * KT;
+        int dy = 0, dx = 0;
+        if (TAPS == 9) {
+            const int tap = ci0 / p.Cin;
+            ci0 -= tap * p.Cin;
+            dy = tap / 3 - 1;
+            dx = tap - (tap / 3) * 3 - 1;
+        }
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            bool ok = a_ok[it];
+            long long off;
+            if (TAPS == 1) {
+                off = a_base[it];
+            } else {
+                const int yy = a_y[it] + dy, xx = a_x[it] + dx;
+                ok = ok && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+                off = (a_base[it] + (long long)yy * p.W + xx) * p.lda;
+            }
+            const int kk = ci0 + a_lc[it] * 4;
+            const float* src = (ok && kk < p.Cin) ? (p.a + off + kk) : zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + (it * 64 + wave_u * 16) * 64), 16, 0, 0);
+        }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            const int row = (tid >> 2) + it * 64;
+            const int nn = n0 + row;
+            const float* src = zero;
+            if (row < BN && nn < p.Npad)
+                src = reinterpret_cast<const float*>(p.w) + (size_t)nn * p.Kpad + (size_t)kt * KT + b_lc[it] * 4;
+            if (BN * 4 >= 256 || wave_u * 16 + it * 64 < BN)     // BN = 32: only waves 0,1 hold rows
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Bs + (it * 64 + wave_u * 16) * 64), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[WM][WN];
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
+    const int lr = lane & 31, lh = lane >> 5;
+
+    auto compute = [&](int stage) {
+        const char* As = smem + stage * STAGE;
+        const char* Bs = As + APAN;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int chunk = 2 * s + lh;
+            f32x4 af[WM], bfr[WN];
+#pragma unroll
+            for (int i = 0; i < WM; ++i) {
+                const int row = (wm * WM + i) * 32 + lr;
+                af[i] = *reinterpret_cast<const f32x4*>(As + (row * 4 + (chunk ^ ((row >> 2) & 3))) * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                const int row = (wn * WN + j) * 32 + lr;
+                bfr[j] = *reinterpret_cast<const f32x4*>(Bs + (row * 4 + (chunk ^ ((row >> 2) & 3))) * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bfr[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bfr[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bfr[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bfr[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+    };
+
+    setup_tile(tile);
+    const int npre = p.ktiles < D ? p.ktiles : D;
+    for (int t = 0; t < npre; ++t) issue_tile(t, t);
+    while (true) {
+        const int m0c = m0, n0c = n0;
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
+
+        int stage = 0, istage = npre % S;
+        for (int kt = 0; kt < p.ktiles; ++kt) {
+            if (kt + D <= p.ktiles) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LPT * (D - 1)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + D < p.ktiles) {
+                issue_tile(kt + D, istage);
+                istage = (istage + 1 == S) ? 0 : istage + 1;
+            }
+            compute(stage);
+            stage = (stage + 1 == S) ? 0 : stage + 1;
+        }
+
+        const bool has_next = (tile + 1) < tile_end;
+        __builtin_amdgcn_s_barrier();            // every wave is done reading the ring (WAR: the
+                                                 // next tile's DMA and the epilogue staging reuse it)
+        if (has_next) {
+            ++tile;
+            setup_tile(tile);
+            for (int t = 0; t < npre; ++t) issue_tile(t, t);
+        }
+
+        UAVSAL_GEMM_EPILOGUE(1.0f, (smem + (S - 1) * STAGE))
         if (!has_next) break;
     }
 }
@@ -411,6 +651,35 @@ int launch_variant(const ConvK& k0, int taps, hipStream_t stream) {
     return uavsal_launch_status();
 }
 
+template <int WAVES_M, int WAVES_N, int WM, int WN, int S>
+int launch_f32_dma(const ConvK& k0, int taps, hipStream_t stream) {
+    constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32;
+    constexpr int SMEM = S * (BM + BN) * 64;
+    ConvK k = k0;
+    const int tiles_m = (k.M + BM - 1) / BM;
+    k.tiles_n = (k.Cout + BN - 1) / BN;
+    k.nblk = tiles_m * k.tiles_n;
+    if (taps == 1) {
+        static const int cap = resident_grid(conv_gemm_f32_dma_kernel<WAVES_M, WAVES_N, WM, WN, 1, S>, SMEM);
+        const int grid = k.nblk < cap ? k.nblk : cap;
+        hipLaunchKernelGGL((conv_gemm_f32_dma_kernel<WAVES_M, WAVES_N, WM, WN, 1, S>), dim3(grid), dim3(256), SMEM, stream, k);
+    } else {
+        static const int cap = resident_grid(conv_gemm_f32_dma_kernel<WAVES_M, WAVES_N, WM, WN, 9, S>, SMEM);
+        const int grid = k.nblk < cap ? k.nblk : cap;
+        hipLaunchKernelGGL((conv_gemm_f32_dma_kernel<WAVES_M, WAVES_N, WM, WN, 9, S>), dim3(grid), dim3(256), SMEM, stream, k);
+    }
+    return uavsal_launch_status();
+}
+
+int launch_f32(const ConvK& k, int taps, int tile, hipStream_t stream) {
+    switch (tile) {
+        case 1: return launch_f32_dma<2, 2, 2, 2, 3>(k, taps, stream);    // 128 x 128, 3 x 16 KB ring
+        case 2: return launch_f32_dma<4, 1, 1, 2, 4>(k, taps, stream);    // 128 x 64,  4 x 12 KB
+        case 3: return launch_f32_dma<4, 1, 1, 1, 4>(k, taps, stream);    // 128 x 32,  4 x 10 KB
+        default: return launch_f32_dma<2, 2, 1, 1, 6>(k, taps, stream);   // 64 x 64,   6 x 8 KB
+    }
+}
+
 template <int PREC>
 int launch_prec(const ConvK& k, int taps, int tile, hipStream_t stream) {
     switch (tile) {
@@ -422,8 +691,10 @@ int launch_prec(const ConvK& k, int taps, int tile, hipStream_t stream) {
 }
 
 int pick_tile(long long M, int Cout) {
-    // largest tile that still gives every CU (256) about two workgroups; N tile no wider
-    // than the (32-padded) channel count needs
+    // Largest tile that still hands every one of the 256 CUs at least one workgroup: measured on
+    // the path's shapes (profiles/r1_gemm_probe.log) 128x128 beats 128x64 / 64x64 as soon as there
+    // are >= 256 tiles (K=1536,N=256: 92 vs 73 TFLOP/s; 3x3 448->256: 91 vs 67), because the
+    // per-tile L2 traffic per FLOP halves.  N tile never wider than the 32-padded channel count.
     const int npad = (Cout + 31) / 32 * 32;
     if (npad <= 32) return 3;
     const int cand_bm[4] = {128, 128, 128, 64};
@@ -431,7 +702,7 @@ int pick_tile(long long M, int Cout) {
     for (int t = 0; t < 4; ++t) {
         if (cand_bn[t] > npad) continue;      // don't waste N
         const long long blocks = ((M + cand_bm[t] - 1) / cand_bm[t]) * ((Cout + cand_bn[t] - 1) / cand_bn[t]);
-        if (blocks >= 512) return t + 1;
+        if (blocks >= 256) return t + 1;
     }
     return 4;
 }
@@ -482,7 +753,7 @@ extern "C" int uavsal_conv_gemm(const uavsal_conv_desc* d, uavsal_stream_t strea
     const int tile = (d->tile >= 1 && d->tile <= 4) ? d->tile : pick_tile(M, d->Cout);
     hipStream_t s = (hipStream_t)stream;
     switch (d->prec) {
-        case UAVSAL_PREC_F32: return launch_prec<UAVSAL_PREC_F32>(k, d->taps, tile, s);
+        case UAVSAL_PREC_F32: return launch_f32(k, d->taps, tile, s);
         case UAVSAL_PREC_BF16X3: return launch_prec<UAVSAL_PREC_BF16X3>(k, d->taps, tile, s);
         case UAVSAL_PREC_F16X3: return launch_prec<UAVSAL_PREC_F16X3>(k, d->taps, tile, s);
         default: return launch_prec<UAVSAL_PREC_BF16>(k, d->taps, tile, s);

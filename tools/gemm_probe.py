@@ -37,6 +37,16 @@ def run(M_hw, n_img, cin, cout, taps, prec, tile, iters=20, act=1, scale=True):
 
 
 if __name__ == "__main__":
+    if os.environ.get("PROBE_NOSTORE"):
+        for K in (256, 512, 1024, 2048):
+            for act in (1, 100):
+                ms, tf = run((45, 80), 8, K, 1536, 1, "f32", 1, act=act)
+                print("K=%d N=1536 act=%d: %.1f us %.1f TF" % (K, act, ms * 1e3, tf), flush=True)
+        for K in (256, 1536):
+            for act in (1, 100):
+                ms, tf = run((45, 80), 8, K, 256, 1, "f32", 1, act=act)
+                print("K=%d N=256 act=%d: %.1f us %.1f TF" % (K, act, ms * 1e3, tf), flush=True)
+        sys.exit(0)
     shapes = [((45, 80), 8, 256, 1536, 1), ((45, 80), 8, 1536, 256, 1), ((45, 80), 8, 4096, 1536, 1),
               ((45, 80), 8, 256, 256, 1), ((45, 80), 8, 448, 256, 9), ((45, 80), 1, 256, 256, 9),
               ((180, 320), 8, 16, 96, 1), ((180, 320), 8, 96, 24, 1), ((45, 80), 64, 256, 1536, 1)]
