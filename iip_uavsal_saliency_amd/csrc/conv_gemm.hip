@@ -101,9 +101,13 @@ __device__ __forceinline__ f32x4 prescale(f32x4 x) {
 // each kernel: handing the accumulator array to a function demotes it to scratch memory.
 #define UAVSAL_GEMM_EPILOGUE(ACC_SCALE, STG)                                                         \
     {                                                                                                \
-        const bool fast_ = p.contig && p.epi == UAVSAL_EPI_AFFINE && p.act != UAVSAL_ACT_SIGMOID;    \
-        const bool vec_ = fast_ && !(p.ldc & 3) && !(p.Cout & 3) && !((size_t)p.out & 15) &&         \
-                          (!p.res || (!(p.ldr & 3) && !((size_t)p.res & 15)));                       \
+        /* the vector ConvTWA update is only compiled into the small-tile kernels (register budget) */ \
+        const bool twa_ = (WM * WN == 1) && p.epi == UAVSAL_EPI_TWA;                                 \
+        const bool vec_ = (p.epi == UAVSAL_EPI_AFFINE || twa_) &&                                    \
+                          p.act != UAVSAL_ACT_SIGMOID && !(p.ldc & 3) && !(p.Cout & 3) &&            \
+                          !((size_t)p.out & 15) &&                                                   \
+                          (!p.res || (!(p.ldr & 3) && !((size_t)p.res & 15))) &&                     \
+                          (!twa_ || (!(p.ldx & 3) && !((size_t)p.aux & 15) && !(p.lda & 3)));        \
         float sc[WN], bi[WN];                                                                        \
         int col[WN];                                                                                 \
         bool cok[WN];                                                                                \
@@ -126,7 +130,7 @@ __device__ __forceinline__ f32x4 prescale(f32x4 x) {
                         _Pragma("unroll") for (int g = 0; g < 16; ++g) {                             \
                             const int r = (g & 3) + 8 * (g >> 2) + 4 * lh;                           \
                             _Pragma("unroll") for (int j = 0; j < WN; ++j)                           \
-                                stg[r * BN + col[j]] =                                               \
+                                stg[r * BN + col[j]] = twa_ ? acc[i][j][g] * (ACC_SCALE) :           \
                                     __builtin_amdgcn_fmed3f(fmaf(acc[i][j][g], sc[j], bi[j]), lo, hi); \
                         }                                                                            \
                     }                                                                                \
@@ -138,8 +142,23 @@ __device__ __forceinline__ f32x4 prescale(f32x4 x) {
                     const int gm = m0c + pp * 32 + row, gn = n0c + c4 * 4;                           \
                     if (row < 32 && gm < p.M && gn < p.Cout) {                                       \
                         f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * BN + c4 * 4);          \
-                        if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (long long)gm * p.ldr + gn); \
-                        *reinterpret_cast<f32x4*>(p.out + (long long)gm * p.ldc + gn) = v;           \
+                        const long long oo = row_off(gm, p.HW, p.o_is, p.contig) * p.ldc + gn;       \
+                        if (twa_) {                                                                  \
+                            const f32x4 z = v + *reinterpret_cast<const f32x4*>(                     \
+                                p.aux + row_off(gm, p.HW, p.x_is, p.contig) * p.ldx + gn);           \
+                            const f32x4 xt = *reinterpret_cast<const f32x4*>(                        \
+                                p.res + row_off(gm, p.HW, p.r_is, p.contig) * p.ldr + gn);           \
+                            const f32x4 hp = *reinterpret_cast<const f32x4*>(                        \
+                                p.a + row_off(gm, p.HW, p.a_is, p.contig) * p.lda + gn);             \
+                            f32x4 gt;                                                                \
+                            gt.x = 1.f / (1.f + expf(-z.x)); gt.y = 1.f / (1.f + expf(-z.y));        \
+                            gt.z = 1.f / (1.f + expf(-z.z)); gt.w = 1.f / (1.f + expf(-z.w));        \
+                            v = gt * xt + (1.f - gt) * hp;                                           \
+                        } else if (p.res) {                                                          \
+                            v += *reinterpret_cast<const f32x4*>(                                    \
+                                p.res + row_off(gm, p.HW, p.r_is, p.contig) * p.ldr + gn);           \
+                        }                                                                            \
+                        *reinterpret_cast<f32x4*>(p.out + oo) = v;                                   \
                     }                                                                                \
                 }                                                                                    \
                 __syncthreads();                                                                     \
@@ -242,15 +261,18 @@ void conv_gemm_kernel(const ConvK p) {
     f32x4 a_reg[A_IT][NLD];
     u32x4 b_reg[B_IT][NPAN];
 
+    int lt_tap = 0, lt_ci = 0;                   // running K position (tiles are loaded in order)
     auto load_tile = [&](int kt) {
-        int ci0 = kt * KT;
+        if (kt == 0) { lt_tap = 0; lt_ci = 0; }
+        const int ci0 = lt_ci;
         int dy = 0, dx = 0;
         if (TAPS == 9) {
-            const int tap = ci0 / p.Cin;
-            ci0 -= tap * p.Cin;
-            dy = tap / 3 - 1;
-            dx = tap - (tap / 3) * 3 - 1;
+            const int ty = (lt_tap * 11) >> 5;              // tap / 3 for tap in 0..9
+            dy = ty - 1;
+            dx = lt_tap - ty * 3 - 1;
         }
+        lt_ci += KT;
+        if (TAPS == 9 && lt_ci >= p.Cin) { lt_ci = 0; ++lt_tap; }
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             bool ok = a_ok[it];
@@ -443,21 +465,23 @@ void conv_gemm_kernel(const ConvK p) {
 // being masked off (a masked lane would leave stale LDS behind).
 __device__ __attribute__((aligned(16))) float g_zero16[4];
 
-template <int WAVES_M, int WAVES_N, int WM, int WN, int TAPS, int S>
+template <int WAVES_M, int WAVES_N, int WM, int WN, int TAPS, int S, int NKP>
 __global__ __launch_bounds__(256, (WM * WN >= 4) ? 3 : 4) void conv_gemm_f32_dma_kernel(const ConvK p) {
     constexpr int BM = WAVES_M * WM * 32;
     constexpr int BN = WAVES_N * WN * 32;
-    constexpr int KT = 16;
+    constexpr int KT = 16;                       // one 64-byte panel row; a stage holds NKP panels
     constexpr int A_IT = (BM * 4) / 256;
     constexpr int B_IT = (BN * 4 + 255) / 256;
-    constexpr int LPT = A_IT + B_IT;             // DMA instructions per thread per K tile
-    constexpr int D = S - 1;                     // prefetch distance in K tiles
+    constexpr int LPT = NKP * (A_IT + B_IT);     // DMA instructions per thread per stage
+    constexpr int D = S - 1;                     // prefetch distance in stages
     constexpr int APAN = BM * 64;
     constexpr int BPAN = BN * 64;
-    constexpr int STAGE = APAN + BPAN;
+    constexpr int PANEL = APAN + BPAN;
+    constexpr int STAGE = NKP * PANEL;
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
-    static_assert((BN * 4) % 256 == 0 || BN * 4 < 256, "B tile shape");
+    static_assert(BN == 32 || BN == 64 || BN == 128, "B tile shape");
     static_assert(LPT * (D - 1) < 64, "vmcnt immediate");
+    static_assert(STAGE >= 32 * BN * 4, "epilogue staging must fit one ring stage");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -504,47 +528,65 @@ __global__ __launch_bounds__(256, (WM * WN >= 4) ? 3 : 4) void conv_gemm_f32_dma
         }
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
-            const int row = (tid >> 2) + it * 64;
+            const int wrow = (BN >= 64) ? (tid >> 6) * 16 : ((tid >> 6) & 1) * 16;
+            const int row = wrow + ((tid & 63) >> 2) + it * 64;
             b_lc[it] = pc ^ ((row >> 2) & 3);
         }
     };
 
-    auto issue_tile = [&](int kt, int stage) {
-        char* As = smem + stage * STAGE;
-        char* Bs = As + APAN;
-        int ci0 = kt * KT;
-        int dy = 0, dx = 0;
-        if (TAPS == 9) {
-            const int tap = ci0 / p.Cin;
-            ci0 -= tap * p.Cin;
-            dy = tap / 3 - 1;
-            dx = tap - (tap / 3) * 3 - 1;
-        }
-#pragma unroll
-        for (int it = 0; it < A_IT; ++it) {
-            bool ok = a_ok[it];
-            long long off;
-            if (TAPS == 1) {
-                off = a_base[it];
-            } else {
-                const int yy = a_y[it] + dy, xx = a_x[it] + dx;
-                ok = ok && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
-                off = (a_base[it] + (long long)yy * p.W + xx) * p.lda;
+    const int kpanels = p.Kpad / KT;             // real 16-wide K panels; stages beyond are zero
+    // running K position of the next panel to request (panels are requested strictly in order,
+    // so no division by Cin is needed to find the tap of a panel)
+    int it_kt = 0, it_tap = 0, it_ci = 0;
+    auto issue_panel = [&](int q, int stage) {
+        {
+            const int kt = it_kt;
+            const bool kin = kt < kpanels;
+            char* As = smem + stage * STAGE + q * PANEL;
+            char* Bs = As + APAN;
+            const int ci0 = it_ci;
+            int dy = 0, dx = 0;
+            if (TAPS == 9) {
+                const int ty = (it_tap * 11) >> 5;          // tap / 3 for tap in 0..9
+                dy = ty - 1;
+                dx = it_tap - ty * 3 - 1;
             }
-            const int kk = ci0 + a_lc[it] * 4;
-            const float* src = (ok && kk < p.Cin) ? (p.a + off + kk) : zero;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + (it * 64 + wave_u * 16) * 64), 16, 0, 0);
-        }
+            ++it_kt;
+            it_ci += KT;
+            if (TAPS == 9 && it_ci >= p.Cin) { it_ci = 0; ++it_tap; }
 #pragma unroll
-        for (int it = 0; it < B_IT; ++it) {
-            const int row = (tid >> 2) + it * 64;
-            const int nn = n0 + row;
-            const float* src = zero;
-            if (row < BN && nn < p.Npad)
-                src = reinterpret_cast<const float*>(p.w) + (size_t)nn * p.Kpad + (size_t)kt * KT + b_lc[it] * 4;
-            if (BN * 4 >= 256 || wave_u * 16 + it * 64 < BN)     // BN = 32: only waves 0,1 hold rows
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Bs + (it * 64 + wave_u * 16) * 64), 16, 0, 0);
+            for (int it = 0; it < A_IT; ++it) {
+                bool ok = a_ok[it] && kin;
+                long long off;
+                if (TAPS == 1) {
+                    off = a_base[it];
+                } else {
+                    const int yy = a_y[it] + dy, xx = a_x[it] + dx;
+                    ok = ok && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+                    off = (a_base[it] + (long long)yy * p.W + xx) * p.lda;
+                }
+                const int kk = ci0 + a_lc[it] * 4;
+                const float* src = (ok && kk < p.Cin) ? (p.a + off + kk) : zero;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + (it * 64 + wave_u * 16) * 64), 16, 0, 0);
+            }
+#pragma unroll
+            for (int it = 0; it < B_IT; ++it) {
+                // BN = 32: the panel has only 32 rows; waves 2,3 re-request the rows of waves 0,1
+                // (identical bytes to identical addresses) so that EVERY wave issues exactly LPT
+                // requests per stage -- the counted s_waitcnt vmcnt below depends on it.
+                const int wrow = (BN >= 64) ? wave_u * 16 : (wave_u & 1) * 16;
+                const int row = wrow + ((tid & 63) >> 2) + it * 64;
+                const int nn = n0 + row;
+                const float* src = zero;
+                if (kin && row < BN && nn < p.Npad)
+                    src = reinterpret_cast<const float*>(p.w) + (size_t)nn * p.Kpad + (size_t)kt * KT + b_lc[it] * 4;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Bs + (it * 64 + wrow) * 64), 16, 0, 0);
+            }
         }
+    };
+    auto issue_tile = [&](int /*st_idx*/, int stage) {
+#pragma unroll
+        for (int q = 0; q < NKP; ++q) issue_panel(q, stage);
     };
 
     f32x16 acc[WM][WN];
@@ -552,37 +594,48 @@ __global__ __launch_bounds__(256, (WM * WN >= 4) ? 3 : 4) void conv_gemm_f32_dma
     const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
     const int lr = lane & 31, lh = lane >> 5;
 
-    auto compute = [&](int stage) {
-        const char* As = smem + stage * STAGE;
-        const char* Bs = As + APAN;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int chunk = 2 * s + lh;
-            f32x4 af[WM], bfr[WN];
+    // Fragment reads are double buffered by hand (sub-step u+1's ds_reads are in flight during
+    // sub-step u's MFMAs) and the next stage's DMA requests are slotted in after each panel: with
+    // one workgroup per CU (the ConvTWA step: 228 tiles) there is no other wave on the SIMD to
+    // cover LDS latency or DMA issue time.
+    auto compute = [&](int stage, bool do_issue, int istage) {
+        f32x4 af[2][WM], bfr[2][WN];
+        auto ld = [&](int u, f32x4 (&a)[WM], f32x4 (&b)[WN]) {
+            const char* As = smem + stage * STAGE + (u >> 1) * PANEL;
+            const char* Bs = As + APAN;
+            const int chunk = 2 * (u & 1) + lh;
 #pragma unroll
             for (int i = 0; i < WM; ++i) {
                 const int row = (wm * WM + i) * 32 + lr;
-                af[i] = *reinterpret_cast<const f32x4*>(As + (row * 4 + (chunk ^ ((row >> 2) & 3))) * 16);
+                a[i] = *reinterpret_cast<const f32x4*>(As + (row * 4 + (chunk ^ ((row >> 2) & 3))) * 16);
             }
 #pragma unroll
             for (int j = 0; j < WN; ++j) {
                 const int row = (wn * WN + j) * 32 + lr;
-                bfr[j] = *reinterpret_cast<const f32x4*>(Bs + (row * 4 + (chunk ^ ((row >> 2) & 3))) * 16);
+                b[j] = *reinterpret_cast<const f32x4*>(Bs + (row * 4 + (chunk ^ ((row >> 2) & 3))) * 16);
             }
+        };
+        ld(0, af[0], bfr[0]);
+#pragma unroll
+        for (int u = 0; u < 2 * NKP; ++u) {
+            if (u + 1 < 2 * NKP) ld(u + 1, af[(u + 1) & 1], bfr[(u + 1) & 1]);
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
                 for (int j = 0; j < WN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bfr[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bfr[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bfr[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bfr[j].w, acc[i][j], 0, 0, 0);
+                    const f32x4 av = af[u & 1][i], bv = bfr[u & 1][j];
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[i][j], 0, 0, 0);
                 }
+            if ((u & 1) && do_issue) issue_panel(u >> 1, istage);
         }
     };
 
     setup_tile(tile);
-    const int npre = p.ktiles < D ? p.ktiles : D;
+    const int nst = (kpanels + NKP - 1) / NKP;   // stages (groups of NKP panels) along K
+    const int npre = nst < D ? nst : D;
     for (int t = 0; t < npre; ++t) issue_tile(t, t);
     while (true) {
         const int m0c = m0, n0c = n0;
@@ -594,15 +647,13 @@ __global__ __launch_bounds__(256, (WM * WN >= 4) ? 3 : 4) void conv_gemm_f32_dma
                 for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
 
         int stage = 0, istage = npre % S;
-        for (int kt = 0; kt < p.ktiles; ++kt) {
-            if (kt + D <= p.ktiles) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LPT * (D - 1)) : "memory");
+        for (int kt = 0; kt < nst; ++kt) {
+            if (kt + D <= nst) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LPT * (D - 1)) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            if (kt + D < p.ktiles) {
-                issue_tile(kt + D, istage);
-                istage = (istage + 1 == S) ? 0 : istage + 1;
-            }
-            compute(stage);
+            const bool do_issue = kt + D < nst;
+            compute(stage, do_issue, istage);
+            if (do_issue) istage = (istage + 1 == S) ? 0 : istage + 1;
             stage = (stage + 1 == S) ? 0 : stage + 1;
         }
 
@@ -612,6 +663,7 @@ __global__ __launch_bounds__(256, (WM * WN >= 4) ? 3 : 4) void conv_gemm_f32_dma
         if (has_next) {
             ++tile;
             setup_tile(tile);
+            it_kt = 0; it_tap = 0; it_ci = 0;
             for (int t = 0; t < npre; ++t) issue_tile(t, t);
         }
 
@@ -651,32 +703,33 @@ int launch_variant(const ConvK& k0, int taps, hipStream_t stream) {
     return uavsal_launch_status();
 }
 
-template <int WAVES_M, int WAVES_N, int WM, int WN, int S>
+template <int WAVES_M, int WAVES_N, int WM, int WN, int S, int NKP>
 int launch_f32_dma(const ConvK& k0, int taps, hipStream_t stream) {
     constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32;
-    constexpr int SMEM = S * (BM + BN) * 64;
+    constexpr int SMEM = S * NKP * (BM + BN) * 64;
     ConvK k = k0;
     const int tiles_m = (k.M + BM - 1) / BM;
     k.tiles_n = (k.Cout + BN - 1) / BN;
     k.nblk = tiles_m * k.tiles_n;
     if (taps == 1) {
-        static const int cap = resident_grid(conv_gemm_f32_dma_kernel<WAVES_M, WAVES_N, WM, WN, 1, S>, SMEM);
+        static const int cap = resident_grid(conv_gemm_f32_dma_kernel<WAVES_M, WAVES_N, WM, WN, 1, S, NKP>, SMEM);
         const int grid = k.nblk < cap ? k.nblk : cap;
-        hipLaunchKernelGGL((conv_gemm_f32_dma_kernel<WAVES_M, WAVES_N, WM, WN, 1, S>), dim3(grid), dim3(256), SMEM, stream, k);
+        hipLaunchKernelGGL((conv_gemm_f32_dma_kernel<WAVES_M, WAVES_N, WM, WN, 1, S, NKP>), dim3(grid), dim3(256), SMEM, stream, k);
     } else {
-        static const int cap = resident_grid(conv_gemm_f32_dma_kernel<WAVES_M, WAVES_N, WM, WN, 9, S>, SMEM);
+        static const int cap = resident_grid(conv_gemm_f32_dma_kernel<WAVES_M, WAVES_N, WM, WN, 9, S, NKP>, SMEM);
         const int grid = k.nblk < cap ? k.nblk : cap;
-        hipLaunchKernelGGL((conv_gemm_f32_dma_kernel<WAVES_M, WAVES_N, WM, WN, 9, S>), dim3(grid), dim3(256), SMEM, stream, k);
+        hipLaunchKernelGGL((conv_gemm_f32_dma_kernel<WAVES_M, WAVES_N, WM, WN, 9, S, NKP>), dim3(grid), dim3(256), SMEM, stream, k);
     }
     return uavsal_launch_status();
 }
 
 int launch_f32(const ConvK& k, int taps, int tile, hipStream_t stream) {
     switch (tile) {
-        case 1: return launch_f32_dma<2, 2, 2, 2, 3>(k, taps, stream);    // 128 x 128, 3 x 16 KB ring
-        case 2: return launch_f32_dma<4, 1, 1, 2, 4>(k, taps, stream);    // 128 x 64,  4 x 12 KB
-        case 3: return launch_f32_dma<4, 1, 1, 1, 4>(k, taps, stream);    // 128 x 32,  4 x 10 KB
-        default: return launch_f32_dma<2, 2, 1, 1, 6>(k, taps, stream);   // 64 x 64,   6 x 8 KB
+        case 1: return launch_f32_dma<2, 2, 2, 2, 3, 1>(k, taps, stream);    // 128 x 128, 3 x 16 KB ring
+        case 2: return launch_f32_dma<4, 1, 1, 2, 4, 1>(k, taps, stream);    // 128 x 64,  4 x 12 KB
+        case 3: return launch_f32_dma<4, 1, 1, 1, 4, 1>(k, taps, stream);    // 128 x 32,  4 x 10 KB
+        default: return launch_f32_dma<2, 2, 1, 1, 3, 4>(k, taps, stream);   // 64 x 64, 3 x (4 x 8 KB): one
+                                                  // workgroup per CU at best, so 64-deep K steps per barrier
     }
 }
 

@@ -57,6 +57,8 @@ CONV1_CASES = [
     (2, 12, 20, 1536, 1, 2, False),    # decoder: Cout=1 + sigmoid
     (3, 7, 5, 320, 256, 1, False),
     (1, 45, 80, 32, 256, 1, True),     # te last_conv + x_sp
+    (2, 45, 80, 1536, 32, 1, False),   # 128x32 tile, long K: every wave must count the same DMA requests
+    (2, 45, 80, 1536, 64, 0, True),    # fucb project
 ]
 
 
