@@ -69,7 +69,12 @@ class LayoutDesc(C.Structure):
                 ("ld", C.c_int32), ("to_nhwc", C.c_int32), ("Cpad", C.c_int32)]
 
 
-DESC_TYPES = [ConvDesc, DwDesc, StemDesc, BilinearDesc, TdiffDesc, TsumDesc, LayoutDesc]
+class PostDesc(C.Structure):
+    _fields_ = [("inp", _f), ("out", _f), ("scratch", _f), ("n_img", C.c_int32), ("h", C.c_int32),
+                ("w", C.c_int32), ("H", C.c_int32), ("W", C.c_int32)]
+
+
+DESC_TYPES = [ConvDesc, DwDesc, StemDesc, BilinearDesc, TdiffDesc, TsumDesc, LayoutDesc, PostDesc]
 
 # every symbol include/uavsal_hip.h declares: (name, restype, argtypes)
 SYMBOLS = [
@@ -81,6 +86,7 @@ SYMBOLS = [
     ("uavsal_tdiff", C.c_int, [C.POINTER(TdiffDesc), C.c_void_p]),
     ("uavsal_tsum", C.c_int, [C.POINTER(TsumDesc), C.c_void_p]),
     ("uavsal_layout", C.c_int, [C.POINTER(LayoutDesc), C.c_void_p]),
+    ("uavsal_postprocess", C.c_int, [C.POINTER(PostDesc), C.c_void_p]),
     ("uavsal_plan_create", C.c_void_p, []),
     ("uavsal_plan_destroy", None, [C.c_void_p]),
     ("uavsal_plan_add_conv", C.c_int, [C.c_void_p, C.POINTER(ConvDesc)]),

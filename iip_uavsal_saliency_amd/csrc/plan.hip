@@ -138,6 +138,7 @@ extern "C" int uavsal_sizeof_desc(int which) {
         case 4: return (int)sizeof(uavsal_tdiff_desc);
         case 5: return (int)sizeof(uavsal_tsum_desc);
         case 6: return (int)sizeof(uavsal_layout_desc);
+        case 7: return (int)sizeof(uavsal_post_desc);
     }
     return UAVSAL_EINVAL;
 }

@@ -178,3 +178,23 @@ def to_nchw(x_nhwc):
     d.inp, d.out, d.n_img, d.C, d.HW, d.ld, d.to_nhwc, d.Cpad = ip, out.data_ptr(), n, c, h * w, ld, 0, 0
     L.check(lib.uavsal_layout(C.byref(d), _stream(out)), "uavsal_layout")
     return out
+
+
+def postprocess_predictions(maps, H, W):
+    """Device version of the caller's post-processing (Demo_Test.py:89-91): `maps` [n,1,h,w] or
+    [n,h,w] fp32 cuda -> uint8 [n,H,W] cuda (resize to the frame size, crop, /max*255, rint)."""
+    lib = L.load()
+    if maps.dim() == 4:
+        maps = maps[:, 0]
+    maps = maps.contiguous()
+    if maps.dtype != torch.float32 or not maps.is_cuda:
+        raise RuntimeError("expected float32 cuda maps")
+    n, h, w = maps.shape
+    out = torch.empty((n, H, W), dtype=torch.uint8, device=maps.device)
+    scratch = torch.empty((n,), dtype=torch.int32, device=maps.device)
+    d = L.PostDesc()
+    d.inp, d.out, d.scratch = maps.data_ptr(), out.data_ptr(), scratch.data_ptr()
+    d.n_img, d.h, d.w, d.H, d.W = n, h, w, H, W
+    L.check(lib.uavsal_postprocess(C.byref(d), _stream(maps)), "uavsal_postprocess")
+    torch.cuda.current_stream(maps.device).synchronize()
+    return out

@@ -195,6 +195,20 @@ typedef struct uavsal_layout_desc {
 
 int uavsal_layout(const uavsal_layout_desc* d, uavsal_stream_t stream);
 
+/*
+ * Output post-processing of the caller, replacing per frame
+ * postprocess_predictions (utils_data.py:289-303: cv2.resize INTER_LINEAR to the source frame
+ * size, centre crop, `img / max(img) * 255`) and np2mat/im2uint8 (utils_data.py:68-82: clip,
+ * round half to even, uint8) as used at Demo_Test.py:89-91.
+ * in: [n_img, h, w] fp32 maps; out: [n_img, H, W] uint8; scratch: >= 4*n_img bytes (zeroed here).
+ */
+typedef struct uavsal_post_desc {
+    const float* in;  uint8_t* out;  void* scratch;
+    int32_t n_img, h, w, H, W;
+} uavsal_post_desc;
+
+int uavsal_postprocess(const uavsal_post_desc* d, uavsal_stream_t stream);
+
 /* ---- launch plan: a recorded sequence of the calls above, run natively ------------ */
 typedef struct uavsal_plan uavsal_plan;
 
@@ -220,7 +234,7 @@ int uavsal_plan_graph_launch(uavsal_plan* p, uavsal_stream_t stream);
 int uavsal_plan_time(uavsal_plan* p, int first, int last, int iters, uavsal_stream_t stream, float* ms);
 
 int uavsal_abi_version(void);
-int uavsal_sizeof_desc(int which); /* 0 conv,1 dw,2 stem,3 bilinear,4 tdiff,5 tsum,6 layout */
+int uavsal_sizeof_desc(int which); /* 0 conv,1 dw,2 stem,3 bilinear,4 tdiff,5 tsum,6 layout,7 post */
 const char* uavsal_build_info(void);
 
 #ifdef __cplusplus

@@ -162,3 +162,44 @@ def test_error_behaviour(hip_model):
         hip_model(x.cuda(), [cb[0][:, :4].cuda(), cb[1].cuda()], None)
     with pytest.raises(RuntimeError):     # CPU tensors: no fallback
         hip_model(x, cb, None)
+
+
+def test_postprocess_matches_numpy_restatement():
+    """Device resize + crop + /max*255 + rint vs oracle/post_ref.py (cv2 itself is not installed:
+    this row is 'parity unpinned', see the oracle's header).  uint8 may differ by one count where
+    the fp32 value sits on a .5 boundary."""
+    from iip_uavsal_saliency_amd import ops
+    from oracle import post_ref
+    g = torch.Generator().manual_seed(3)
+    for (h, w, H, W) in [(45, 80, 360, 640), (45, 80, 300, 640), (45, 80, 720, 1000), (36, 64, 288, 512)]:
+        maps = torch.rand((3, 1, h, w), generator=g) * 0.9 + 0.05
+        got = ops.postprocess_predictions(maps.cuda(), H, W).cpu().numpy()
+        for i in range(3):
+            ref = post_ref.to_uint8(post_ref.postprocess_predictions(maps[i, 0].numpy(), H, W))
+            diff = np.abs(got[i].astype(np.int32) - ref.astype(np.int32))
+            assert diff.max() <= 1 and (diff > 0).mean() < 2e-3, (h, w, H, W, diff.max(), (diff > 0).mean())
+            assert got[i].max() == 255
+
+
+def test_predict_video_equals_manual_loop(hip_model, oracle):
+    """The streaming driver == the reference caller's loop (Demo_Test.py:65-95) run by hand on the oracle."""
+    from iip_uavsal_saliency_amd.stream import predict_video
+    from oracle import post_ref
+    T, H, W = 2, 72, 104
+    u8 = synth.synth_frames_u8(9, H, W)          # 9 frames, time_dims 2 -> 8 kept, groups of 4
+    gp = torch.from_numpy(synth.gauss_priors(1, 9, 13))[0]
+    op = torch.from_numpy(synth.ob_priors(1, 9, 13))[0]
+    hip_model.time_dims, hip_model.precision = T, "f32"
+    sal, maps = predict_video(hip_model, torch.from_numpy(u8), gp, op, batch_size=2, return_maps=True)
+    assert sal.shape == (8, H, W) and sal.dtype == torch.uint8
+    oracle.time_dims = T
+    state, ref_maps = None, []
+    for i in range(2):
+        x = torch.from_numpy(synth.normalize_frames(u8[i * 4:(i + 1) * 4]))
+        cb = [gp.unsqueeze(0).repeat(4, 1, 1, 1), op.unsqueeze(0).repeat(4, 1, 1, 1)]
+        o, state = oracle(x, cb, state)
+        ref_maps.append(o)
+    ref_maps = torch.cat(ref_maps, 0)
+    assert (maps.cpu() - ref_maps).abs().max().item() <= MAP_TOL["f32"]
+    ref0 = post_ref.to_uint8(post_ref.postprocess_predictions(ref_maps[0, 0].numpy(), H, W))
+    assert np.abs(sal[0].cpu().numpy().astype(np.int32) - ref0.astype(np.int32)).max() <= 2
