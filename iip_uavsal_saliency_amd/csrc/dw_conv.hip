@@ -170,6 +170,6 @@ extern "C" int uavsal_dw3x3(const uavsal_dw_desc* d, uavsal_stream_t stream) {
         hipLaunchKernelGGL(dw3x3_dilated_kernel, dim3(k.nblk), dim3(256), 0, s, k);
         return uavsal_launch_status();
     }
-    if (d->stride == 1) return launch_dw<1, 2, 4>(k, s);
+    if (d->stride == 1) return launch_dw<1, 4, 4>(k, s);
     return launch_dw<2, 2, 2>(k, s);
 }
