@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(PKG, "libuavsal_hip.so")
 
 PREC = {"f32": 0, "bf16x3": 1, "bf16": 2, "f16x3": 3}
 ACT_NONE, ACT_RELU6, ACT_SIGMOID = 0, 1, 2
-EPI_AFFINE, EPI_TWA = 0, 1
+EPI_AFFINE, EPI_TWA, EPI_LSTM = 0, 1, 2
 
 _ERR = {-1: "UAVSAL_EINVAL (null pointer / non-positive size)",
         -2: "UAVSAL_EALIGN (channel count / ld / pointer not 16-byte aligned)",
@@ -31,7 +31,8 @@ class ConvDesc(C.Structure):
                 ("aux", _f), ("ldx", C.c_int32), ("x_img_stride", C.c_int64),
                 ("n_img", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
                 ("Cin", C.c_int32), ("Cout", C.c_int32), ("taps", C.c_int32),
-                ("prec", C.c_int32), ("act", C.c_int32), ("epi", C.c_int32), ("tile", C.c_int32)]
+                ("prec", C.c_int32), ("act", C.c_int32), ("epi", C.c_int32), ("tile", C.c_int32),
+                ("out2", _f), ("ld2", C.c_int32)]
 
 
 class DwDesc(C.Structure):
@@ -123,7 +124,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.uavsal_abi_version() != 1:
+    if lib.uavsal_abi_version() != 2:
         raise RuntimeError("libuavsal_hip.so ABI version mismatch")
     for i, t in enumerate(DESC_TYPES):
         if lib.uavsal_sizeof_desc(i) != C.sizeof(t):

@@ -40,8 +40,9 @@ struct ConvK {
     float* out;
     const float* res;
     const float* aux;
+    float* out2;
     long long a_is, o_is, r_is, x_is;
-    int lda, ldc, ldr, ldx;
+    int lda, ldc, ldr, ldx, ld2;
     int M, HW, H, W, Cin, Cout, Kpad, Npad, ktiles, act, epi;
     int tiles_n, nblk, contig;
 };
@@ -103,7 +104,8 @@ __device__ __forceinline__ f32x4 prescale(f32x4 x) {
     {                                                                                                \
         /* the vector ConvTWA update is only compiled into the small-tile kernels (register budget) */ \
         const bool twa_ = (WM * WN == 1) && p.epi == UAVSAL_EPI_TWA;                                 \
-        const bool vec_ = (p.epi == UAVSAL_EPI_AFFINE || twa_) &&                                    \
+        const bool lstm_ = (WM * WN == 1) && p.epi == UAVSAL_EPI_LSTM;                               \
+        const bool vec_ = (p.epi == UAVSAL_EPI_AFFINE || twa_ || lstm_) &&                           \
                           p.act != UAVSAL_ACT_SIGMOID && !(p.ldc & 3) && !(p.Cout & 3) &&            \
                           !((size_t)p.out & 15) &&                                                   \
                           (!p.res || (!(p.ldr & 3) && !((size_t)p.res & 15))) &&                     \
@@ -130,7 +132,7 @@ __device__ __forceinline__ f32x4 prescale(f32x4 x) {
                         _Pragma("unroll") for (int g = 0; g < 16; ++g) {                             \
                             const int r = (g & 3) + 8 * (g >> 2) + 4 * lh;                           \
                             _Pragma("unroll") for (int j = 0; j < WN; ++j)                           \
-                                stg[r * BN + col[j]] = twa_ ? acc[i][j][g] * (ACC_SCALE) :           \
+                                stg[r * BN + col[j]] = (twa_ || lstm_) ? acc[i][j][g] * (ACC_SCALE) : \
                                     __builtin_amdgcn_fmed3f(fmaf(acc[i][j][g], sc[j], bi[j]), lo, hi); \
                         }                                                                            \
                     }                                                                                \
@@ -143,6 +145,19 @@ __device__ __forceinline__ f32x4 prescale(f32x4 x) {
                     if (row < 32 && gm < p.M && gn < p.Cout) {                                       \
                         f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * BN + c4 * 4);          \
                         const long long oo = row_off(gm, p.HW, p.o_is, p.contig) * p.ldc + gn;       \
+                        if (lstm_) {                                                                 \
+                            const f32x4 z = v + *reinterpret_cast<const f32x4*>(                     \
+                                p.aux + row_off(gm, p.HW, p.x_is, p.contig) * p.ldx + gn);           \
+                            const int ch = gn >> 2;                                                  \
+                            const float cp = p.res[row_off(gm, p.HW, p.r_is, p.contig) * p.ldr + ch]; \
+                            const float ig = 1.f / (1.f + expf(-z.x)), fg = 1.f / (1.f + expf(-z.y)); \
+                            const float og = 1.f / (1.f + expf(-z.z)), gg = tanhf(z.w);              \
+                            const float cn = fg * cp + ig * gg;                                      \
+                            const long long ho = row_off(gm, p.HW, p.o_is, p.contig);                \
+                            p.out[ho * p.ldc + ch] = og * tanhf(cn);                                 \
+                            p.out2[ho * p.ld2 + ch] = cn;                                            \
+                            continue;                                                                \
+                        }                                                                            \
                         if (twa_) {                                                                  \
                             const f32x4 z = v + *reinterpret_cast<const f32x4*>(                     \
                                 p.aux + row_off(gm, p.HW, p.x_is, p.contig) * p.ldx + gn);           \
@@ -764,6 +779,7 @@ int pick_tile(long long M, int Cout) {
 
 extern "C" int uavsal_conv_tile(const uavsal_conv_desc* d) {
     if (!d || d->n_img <= 0 || d->H <= 0 || d->W <= 0 || d->Cout <= 0) return UAVSAL_EINVAL;
+    if (d->epi == UAVSAL_EPI_LSTM) return 4;
     if (d->tile >= 1 && d->tile <= 4) return d->tile;
     return pick_tile((long long)d->H * d->W * d->n_img, d->Cout);
 }
@@ -774,13 +790,18 @@ extern "C" int uavsal_conv_gemm(const uavsal_conv_desc* d, uavsal_stream_t strea
     if (d->taps != 1 && d->taps != 9) return UAVSAL_ESHAPE;
     if (d->prec < 0 || d->prec > 3) return UAVSAL_ESHAPE;
     if ((d->Cin & 3) || (d->lda & 3) || d->lda < d->Cin) return UAVSAL_EALIGN;
-    if (d->ldc < d->Cout) return UAVSAL_ESHAPE;
+    if (d->epi != UAVSAL_EPI_LSTM && d->ldc < d->Cout) return UAVSAL_ESHAPE;
     if (!uavsal_aligned16(d->a) || !uavsal_aligned16(d->w)) return UAVSAL_EALIGN;
     if (d->taps == 9 && (d->Cin % 32)) return UAVSAL_ESHAPE;
     if ((d->scale == nullptr) != (d->bias == nullptr)) return UAVSAL_EINVAL;
-    if (d->res && d->ldr < d->Cout) return UAVSAL_ESHAPE;
+    if (d->res && d->epi != UAVSAL_EPI_LSTM && d->ldr < d->Cout) return UAVSAL_ESHAPE;
     if (d->epi == UAVSAL_EPI_TWA) {
         if (!d->res || !d->aux || d->Cin != d->Cout || d->ldx < d->Cout) return UAVSAL_ESHAPE;
+    } else if (d->epi == UAVSAL_EPI_LSTM) {
+        if (!d->res || !d->aux || !d->out2 || (d->Cout & 3) || d->Cin * 4 != d->Cout) return UAVSAL_ESHAPE;
+        if (d->ldc < d->Cin || d->ld2 < d->Cin || d->ldr < d->Cin || d->ldx < d->Cout) return UAVSAL_ESHAPE;
+        if ((d->ldx & 3) || (d->ldc & 3) || (d->ldr & 3) || !uavsal_aligned16(d->aux) ||
+            !uavsal_aligned16(d->out) || !uavsal_aligned16(d->res)) return UAVSAL_EALIGN;
     } else if (d->epi != UAVSAL_EPI_AFFINE) {
         return UAVSAL_ESHAPE;
     }
@@ -791,7 +812,7 @@ extern "C" int uavsal_conv_gemm(const uavsal_conv_desc* d, uavsal_stream_t strea
 
     ConvK k;
     k.a = d->a; k.w = (const char*)d->w; k.scale = d->scale; k.bias = d->bias;
-    k.out = d->out; k.res = d->res; k.aux = d->aux;
+    k.out = d->out; k.res = d->res; k.aux = d->aux; k.out2 = d->out2; k.ld2 = d->ld2;
     k.a_is = d->a_img_stride; k.o_is = d->o_img_stride;
     k.r_is = d->res ? d->r_img_stride : HW; k.x_is = d->aux ? d->x_img_stride : HW;
     k.lda = d->lda; k.ldc = d->ldc; k.ldr = d->ldr; k.ldx = d->ldx;
@@ -803,7 +824,8 @@ extern "C" int uavsal_conv_gemm(const uavsal_conv_desc* d, uavsal_stream_t strea
     k.act = d->act; k.epi = d->epi;
     k.contig = (k.a_is == HW && k.o_is == HW && k.r_is == HW && k.x_is == HW) ? 1 : 0;
     k.tiles_n = 0; k.nblk = 0;
-    const int tile = (d->tile >= 1 && d->tile <= 4) ? d->tile : pick_tile(M, d->Cout);
+    int tile = (d->tile >= 1 && d->tile <= 4) ? d->tile : pick_tile(M, d->Cout);
+    if (d->epi == UAVSAL_EPI_LSTM) tile = 4;     // the LSTM update lives in the 64x64 tile's vector epilogue
     hipStream_t s = (hipStream_t)stream;
     switch (d->prec) {
         case UAVSAL_PREC_F32: return launch_f32(k, d->taps, tile, s);

@@ -132,12 +132,15 @@ class Engine:
             self._wcache[key] = (self._dev(P.pad_vec(s, n, 1.0)), self._dev(P.pad_vec(b, n, 0.0)))
         return self._wcache[key]
 
-    def _convw(self, conv, sl=None):
-        key = ("w", id(conv), sl, self.prec_name)
+    def _convw(self, conv, sl=None, gate_interleave=0):
+        key = ("w", id(conv), sl, self.prec_name, gate_interleave)
         if key not in self._wcache:
             w = conv.weight.detach()
             if sl is not None:
                 w = w[:, sl[0]:sl[1]]
+            if gate_interleave:      # ConvLSTM: row g*hid + c  ->  4*c + g  (gates i,f,o,g adjacent)
+                hid = gate_interleave
+                w = w.reshape(4, hid, *w.shape[1:]).permute(1, 0, 2, 3, 4).reshape(4 * hid, *w.shape[1:])
             self._wcache[key] = self._dev(P.pack_conv_weight(w, self.prec_name))
         return self._wcache[key]
 
@@ -151,8 +154,10 @@ class Engine:
             L.check(r, what)
 
     def conv(self, name, a: V, conv, bn, out: V, act, taps=1, res: Optional[V] = None, wslice=None,
-             epi=L.EPI_AFFINE, aux: Optional[V] = None, n_img=None, strides=None):
-        cin, cout = a.c, out.c
+             epi=L.EPI_AFFINE, aux: Optional[V] = None, n_img=None, strides=None, cout=None,
+             out2: Optional[V] = None, gate_interleave=0):
+        cin = a.c
+        cout = out.c if cout is None else cout
         n_img = a.n if n_img is None else n_img
         hw = a.h * a.w
         flops = 2.0 * n_img * hw * cin * cout * taps
@@ -164,7 +169,7 @@ class Engine:
         d = L.ConvDesc()
         st = strides or {}
         d.a, d.lda, d.a_img_stride = a.ptr, a.ld, st.get("a", hw)
-        d.w = self._convw(conv, wslice).data_ptr()
+        d.w = self._convw(conv, wslice, gate_interleave).data_ptr()
         if bn is not None:
             s, b = self._affine(bn, cout)
             d.scale, d.bias = s.data_ptr(), b.data_ptr()
@@ -182,6 +187,8 @@ class Engine:
         d.n_img, d.H, d.W = n_img, a.h, a.w
         d.Cin, d.Cout, d.taps = cin, cout, taps
         d.prec, d.act, d.epi, d.tile = self.prec, act, epi, 0
+        if out2 is not None:
+            d.out2, d.ld2 = out2.ptr, out2.ld
         self.ops_meta[-1]["tile"] = int(self.lib.uavsal_conv_tile(C.byref(d)))
         self._add(self.lib.uavsal_plan_add_conv, d, "plan_add_conv(%s)" % name)
 
@@ -257,6 +264,8 @@ class Engine:
             self.cb1_in = torch.empty((N, 20, h, w), dtype=torch.float32, device=dev)
             self.state_in = torch.zeros((self.n_seq, 256, h, w), dtype=torch.float32, device=dev)
             self.state_out = torch.empty((self.n_seq, 256, h, w), dtype=torch.float32, device=dev)
+            self.cstate_in = torch.zeros((self.n_seq, 256, h, w), dtype=torch.float32, device=dev)
+            self.cstate_out = torch.empty((self.n_seq, 256, h, w), dtype=torch.float32, device=dev)
             self.out = torch.empty((N, hw), dtype=torch.float32, device=dev)
             self.logits = torch.empty((N, hw), dtype=torch.float32, device=dev) if self.keep_taps else None
         feats = m.sfnet.features.features
@@ -264,13 +273,17 @@ class Engine:
         # ---- boundary: state and priors NCHW -> NHWC
         s0 = len(self.ops_meta)
         h0 = self._buf("h0", self.n_seq, h, w, 256)
+        lstm_model = getattr(m, "rnn_type", "twa") == "lstm"
+        c0 = self._buf("c0", self.n_seq, h, w, 256) if lstm_model else None
         g0 = self._buf("gauss_in", N, h, w, 8)
         o0 = self._buf("ob_in", N, h, w, 20)
         if self._dry:
-            for nm, c in (("state.in", 256), ("gauss.in", 8), ("ob.in", 20)):
+            for nm, c in (("state.in", 256), ("gauss.in", 8), ("ob.in", 20)) + ((("cstate.in", 256),) if lstm_model else ()):
                 self._meta(kind="layout", name=nm, flops=0.0, bytes=8.0 * N * c * hw)
         else:
             self.layout("state.in", self.state_in.data_ptr(), h0.ptr, self.n_seq, 256, hw, 256, 1)
+            if lstm_model:
+                self.layout("cstate.in", self.cstate_in.data_ptr(), c0.ptr, self.n_seq, 256, hw, 256, 1)
             self.layout("gauss.in", self.cb0_in.data_ptr(), g0.ptr, N, 8, hw, 8, 1)
             self.layout("ob.in", self.cb1_in.data_ptr(), o0.ptr, N, 20, hw, 20, 1)
         self._mark("boundary_in", s0)
@@ -388,14 +401,31 @@ class Engine:
         self.ir_block("fucbst", fu, m.fucbst_layer[0], xf)
         self._mark("prior_fuse", s0)
 
-        # ---- ConvTWA recurrence (model_convlstm.py:276-292, 368-371)
+        # ---- recurrence: ConvTWA (model_convlstm.py:276-292, 368-371) or ConvLSTM (:111-126, 206-222)
         s0 = len(self.ops_meta)
         rc = m.rnn.cell_list[0].rnn_conv
-        pre = self._buf("twa_pre", N, h, w, 256)
-        self.conv("twa.wx", xf, rc, None, pre, NONE, taps=9, wslice=(0, 256))        # W[:, :256] * x_t, all t
-        ro = self._buf("rnn", N, h, w, 256)
         Lq = self.seq_len
-        for t in range(Lq):
+        ro = self._buf("rnn", N, h, w, 256)
+        lstm = getattr(m, "rnn_type", "twa") == "lstm"
+        if lstm:
+            pre = self._buf("lstm_pre", N, h, w, 1024)      # W[:, :256] * x_t for all t, rows 4*c+gate
+            self.conv("lstm.wx", xf, rc, None, pre, NONE, taps=9, wslice=(0, 256), gate_interleave=256)
+            co = self._buf("lstm_c", N, h, w, 256)          # cell-state history
+            for t in range(Lq):
+                hp = self.named["h0"] if t == 0 else ro.frames(t - 1, self.n_seq)
+                cp = c0 if t == 0 else co.frames(t - 1, self.n_seq)
+                a = V(hp.t, self.n_seq, h, w, 256, 256, hp.coff)
+                st = hw if t == 0 else Lq * hw
+                strides = {"a": st, "r": st, "o": Lq * hw, "x": Lq * hw}
+                self.conv("lstm.step%d" % t, a, rc, None, ro.frames(t, self.n_seq), NONE, taps=9,
+                          wslice=(256, 512), gate_interleave=256, epi=L.EPI_LSTM, cout=1024,
+                          res=V(cp.t, self.n_seq, h, w, 256, 256, cp.coff), aux=pre.frames(t, self.n_seq),
+                          out2=co.frames(t, self.n_seq), n_img=self.n_seq, strides=strides)
+            self.named["lstm_c"] = co
+        else:
+            pre = self._buf("twa_pre", N, h, w, 256)
+            self.conv("twa.wx", xf, rc, None, pre, NONE, taps=9, wslice=(0, 256))    # W[:, :256] * x_t, all t
+        for t in range(0 if lstm else Lq):
             a = h0 if t == 0 else ro.frames(t - 1, self.n_seq)
             a = V(a.t, self.n_seq, h, w, 256, 256, a.coff)
             strides = {"a": hw if t == 0 else Lq * hw, "o": Lq * hw, "r": Lq * hw, "x": Lq * hw}
@@ -411,12 +441,14 @@ class Engine:
             lv = V(_Fake() if self._dry else self.logits, N, h, w, 1)
             self.ir_block("conv_out_st.logits", ro, m.conv_out_st, lv, final_act=NONE)
         self.ir_block("conv_out_st", ro, m.conv_out_st, outv, final_act=L.ACT_SIGMOID)
+        outs = [(ro, "state_out")] + ([(self.named["lstm_c"], "cstate_out")] if lstm else [])
         for c in range(self.n_seq):
-            last = ro.frames(c * Lq + Lq - 1, 1)
-            if self._dry:
-                self._meta(kind="layout", name="state.out", flops=0.0, bytes=8.0 * 256 * hw)
-            else:
-                self.layout("state.out", last.ptr, self.state_out.data_ptr() + 4 * c * 256 * hw, 1, 256, hw, 256, 0)
+            for hist, dst in outs:
+                last = hist.frames(c * Lq + Lq - 1, 1)
+                if self._dry:
+                    self._meta(kind="layout", name="state.out", flops=0.0, bytes=8.0 * 256 * hw)
+                else:
+                    self.layout("state.out", last.ptr, getattr(self, dst).data_ptr() + 4 * c * 256 * hw, 1, 256, hw, 256, 0)
         self._mark("decoder", s0)
 
     # ------------------------------------------------------------------ execution
@@ -444,7 +476,7 @@ class Engine:
         else:
             L.check(self.lib.uavsal_plan_run(self.plan, 0, -1, self._stream()), "plan_run")
 
-    def stage_inputs(self, x, cb0, cb1, state):
+    def stage_inputs(self, x, cb0, cb1, state, cstate=None):
         self.x_in.copy_(x.reshape(self.x_in.shape))
         self.cb0_in.copy_(cb0.reshape(self.cb0_in.shape))
         self.cb1_in.copy_(cb1.reshape(self.cb1_in.shape))
@@ -452,15 +484,21 @@ class Engine:
             self.state_in.zero_()
         else:
             self.state_in.copy_(state.reshape(self.state_in.shape))
+        if cstate is None:
+            self.cstate_in.zero_()
+        else:
+            self.cstate_in.copy_(cstate.reshape(self.cstate_in.shape))
 
-    def run(self, x, cb0, cb1, state=None, taps: Optional[dict] = None):
+    def run(self, x, cb0, cb1, state=None, taps: Optional[dict] = None, cstate=None):
         if x.dtype != self.in_dtype:
             raise RuntimeError("engine built for %s frames, got %s" % (self.in_dtype, x.dtype))
         with torch.cuda.device(self.device):
-            self.stage_inputs(x, cb0, cb1, state)
+            self.stage_inputs(x, cb0, cb1, state, cstate)
             self.launch()
             out = self.out.clone()
             st = self.state_out.clone()
+            if getattr(self.model, "rnn_type", "twa") == "lstm":
+                st = (st, self.cstate_out.clone())
             if taps is not None:
                 if not self.keep_taps:
                     raise RuntimeError("engine was built without taps")

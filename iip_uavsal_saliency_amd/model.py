@@ -23,7 +23,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .model_convlstm import ConvTWA
+from .model_convlstm import ConvLSTM, ConvTWA
 from .model_feature import ReMobileNetV2, _no_eager
 
 feature_inplanes = {"mobilenet_v2": [24, 32, 96, 320]}       # reference model.py:32
@@ -150,6 +150,7 @@ class STBlock(nn.Module):
 
 class UAVSal(nn.Module):
     """See module docstring.  Constructor arguments as reference model.py:255-261."""
+    rnn_type = "twa"
 
     def __init__(self, cnn_type="mobilenet_v2", time_dims=5, num_stblock=2, bias_type=[1, 1, 1],
                  iosize=[360, 640, 45, 80], planes=256, pre_model_path="", precision="f32"):
@@ -179,7 +180,8 @@ class UAVSal(nn.Module):
         self.fucb_layer = nn.Sequential(dwBlock(192, planes // 4, kernel_size=3))
         self.fucbst_layer = nn.Sequential(dwBlock(planes + planes // 4, planes, kernel_size=3))
         _, _, shape_r_out, shape_c_out = iosize
-        self.rnn = ConvTWA((shape_r_out, shape_c_out), planes, planes, kernel_size=(3, 3), num_layers=1,
+        rnn_cls = ConvLSTM if self.rnn_type == "lstm" else ConvTWA
+        self.rnn = rnn_cls((shape_r_out, shape_c_out), planes, planes, kernel_size=(3, 3), num_layers=1,
                            batch_first=True, bias=False, return_all_layers=False)
         self.conv_out_st = dwBlock(planes, 1, kernel_size=3)
         init_weights(self.st_layer, "kaiming_normal", mode="fan_out")
@@ -211,7 +213,7 @@ class UAVSal(nn.Module):
     def _engine(self, device, n_seq, seq_len, H, W, ctx_mode, taps=False, in_dtype=torch.float32):
         from .engine import Engine
         key = (str(device), n_seq, seq_len, H, W, self.time_dims if ctx_mode == "tile" else seq_len,
-               ctx_mode, self.precision, bool(taps), in_dtype, bool(self.use_graph))
+               ctx_mode, self.precision, bool(taps), in_dtype, bool(self.use_graph), self.rnn_type)
         eng = self._engines.get(key)
         if eng is None:
             eng = Engine(self, device, n_seq=n_seq, seq_len=seq_len, H=H, W=W,
@@ -248,12 +250,16 @@ class UAVSal(nn.Module):
         eng = self._engine(x.device, 1, n, H, W, "tile", taps is not None, x.dtype)
         h, w = eng.h, eng.w
         self._check_cb(cb, n, h, w)
-        st = None
+        st, cst = None, None
         if in_state is not None:
             st = in_state[0]
-            if tuple(st.shape) != (1, 256, h, w):
-                raise RuntimeError("in_state[0] must be [1, 256, %d, %d]" % (h, w))
-        out, state = eng.run(x, cb[0], cb[1], st, taps)
+            if self.rnn_type == "lstm":           # reference ConvLSTM: hidden_state[0] = (h, c)
+                st, cst = st
+            if tuple(st.shape) != (1, 256, h, w) or (cst is not None and tuple(cst.shape) != (1, 256, h, w)):
+                raise RuntimeError("in_state tensors must be [1, 256, %d, %d]" % (h, w))
+        out, state = eng.run(x, cb[0], cb[1], st, taps, cstate=cst)
+        if self.rnn_type == "lstm":               # reference returns last_state_list[-1] = [h, c]
+            return out.view(n, 1, h, w), [state[0].view(1, 256, h, w), state[1].view(1, 256, h, w)]
         return out.view(n, 1, h, w), [state.view(1, 256, h, w)]
 
     @torch.no_grad()
@@ -270,10 +276,15 @@ class UAVSal(nn.Module):
         eng = self._engine(x.device, C, T, H, W, "clip", taps is not None, x.dtype)
         h, w = eng.h, eng.w
         self._check_cb([cb[0].reshape(C * T, *cb[0].shape[2:]), cb[1].reshape(C * T, *cb[1].shape[2:])], C * T, h, w)
+        cst = None
+        if self.rnn_type == "lstm" and states is not None:
+            states, cst = states                 # (h [C,256,h,w], c [C,256,h,w])
         if states is not None and tuple(states.shape) != (C, 256, h, w):
             raise RuntimeError("states must be [C, 256, h, w]")
         out, state = eng.run(x.reshape(C * T, 3, H, W), cb[0].reshape(C * T, 8, h, w),
-                             cb[1].reshape(C * T, 20, h, w), states, taps)
+                             cb[1].reshape(C * T, 20, h, w), states, taps, cstate=cst)
+        if self.rnn_type == "lstm":
+            return out.view(C, T, 1, h, w), (state[0].view(C, 256, h, w), state[1].view(C, 256, h, w))
         return out.view(C, T, 1, h, w), state.view(C, 256, h, w)
 
     @staticmethod
@@ -285,3 +296,10 @@ class UAVSal(nn.Module):
                 n, h, w, n, h, w, tuple(cb[0].shape), tuple(cb[1].shape)))
         if cb[0].dtype != torch.float32 or cb[1].dtype != torch.float32:
             raise RuntimeError("cb tensors must be float32")
+
+
+class UAVSAL_LSTM(UAVSal):
+    """The reference's ConvLSTM ablation model (reference model.py:960-1076): identical to UAVSal
+    except `self.rnn = ConvLSTM(...)` (model.py:1029); `in_state` is None or `[(h, c)]`, the returned
+    state is `[h, c]` (model_convlstm.py:206-222)."""
+    rnn_type = "lstm"

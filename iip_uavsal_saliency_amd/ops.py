@@ -198,3 +198,30 @@ def postprocess_predictions(maps, H, W):
     L.check(lib.uavsal_postprocess(C.byref(d), _stream(maps)), "uavsal_postprocess")
     torch.cuda.current_stream(maps.device).synchronize()
     return out
+
+
+def lstm_step(x_t, h_prev, c_prev, weight, prec="f32"):
+    """One ConvLSTM step (reference model_convlstm.py:111-126, bias=False) from NHWC tensors and the
+    reference-layout weight [4*hid, in+hid, 3, 3]: returns (h_t, c_t).  The x half of the conv is
+    hoisted exactly as the engine does (`aux`), gates interleaved as n = 4*c + gate."""
+    lib = L.load()
+    ap, lda, n, h, w, hid = _nhwc_view(h_prev)
+    cin = x_t.shape[3]
+    wi = weight.reshape(4, hid, cin + hid, 3, 3).permute(1, 0, 2, 3, 4).reshape(4 * hid, cin + hid, 3, 3)
+    pre = conv_gemm(x_t, wi[:, :cin].contiguous(), None, None, prec=prec)       # [n,h,w,4*hid]
+    cp, ldr, *_ = _nhwc_view(c_prev)
+    h_out = torch.empty((n, h, w, hid), dtype=torch.float32, device=x_t.device)
+    c_out = torch.empty_like(h_out)
+    wp = P.pack_conv_weight(wi[:, cin:].contiguous(), prec).to(x_t.device)
+    d = L.ConvDesc()
+    d.a, d.lda, d.a_img_stride = ap, lda, h * w
+    d.w = wp.data_ptr()
+    d.out, d.ldc, d.o_img_stride = h_out.data_ptr(), hid, h * w
+    d.out2, d.ld2 = c_out.data_ptr(), hid
+    d.res, d.ldr, d.r_img_stride = cp, ldr, h * w
+    d.aux, d.ldx, d.x_img_stride = pre.data_ptr(), 4 * hid, h * w
+    d.n_img, d.H, d.W, d.Cin, d.Cout, d.taps = n, h, w, hid, 4 * hid, 9
+    d.prec, d.act, d.epi, d.tile = L.PREC[prec], L.ACT_NONE, L.EPI_LSTM, 0
+    L.check(lib.uavsal_conv_gemm(C.byref(d), _stream(x_t)), "uavsal_conv_gemm(LSTM)")
+    torch.cuda.current_stream(x_t.device).synchronize()
+    return h_out, c_out

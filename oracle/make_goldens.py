@@ -80,9 +80,10 @@ def weights_digest(model):
     return hsh.hexdigest()
 
 
-def run_case(ref_model, name, H, W, T, B=1, seed=0, tap_stride=13, state_stride=3, calls=1):
+def run_case(ref_model, name, H, W, T, B=1, seed=0, tap_stride=13, state_stride=3, calls=1, cls="UAVSal"):
     n = B * T
-    model = ref_model.UAVSal(cnn_type="mobilenet_v2", time_dims=T, num_stblock=2, bias_type=[1, 1, 1],
+    lstm = cls == "UAVSAL_LSTM"
+    model = getattr(ref_model, cls)(cnn_type="mobilenet_v2", time_dims=T, num_stblock=2, bias_type=[1, 1, 1],
                              iosize=[H, W, H // 8, W // 8], planes=256, pre_model_path="")
     synth.load_synth_weights(model, seed)
     model.eval()
@@ -108,8 +109,13 @@ def run_case(ref_model, name, H, W, T, B=1, seed=0, tap_stride=13, state_stride=
     with torch.no_grad():
         for c in range(calls):
             x, cb, zero = inputs(n, H, W, seed, t0=c * n)
-            out, st = model(x, cb, [zero] if state is None else state)
-            state = [st[0].detach()]
+            if lstm:     # ConvLSTM.forward unpacks hidden_state[0] as (h, c) (model_convlstm.py:204)
+                out, st = model(x, cb, [(zero, zero.clone())] if state is None else state)
+                rec["cstate" + ("" if c == 0 else f"_call{c}")] = sub(st[1], state_stride)
+                state = [(st[0].detach(), st[1].detach())]
+            else:
+                out, st = model(x, cb, [zero] if state is None else state)
+                state = [st[0].detach()]
             sfx = "" if c == 0 else f"_call{c}"
             rec["out" + sfx] = out.numpy().astype(np.float32)
             rec["logits" + sfx] = taps["logits"].numpy().astype(np.float32)
@@ -151,6 +157,7 @@ def main():
     run_case(ref_model, "e2e_96x160_B4T5", 96, 160, 5, B=4, tap_stride=61)             # Demo_Test.py default chunking
     run_case(ref_model, "e2e_96x160_T4_two_calls", 96, 160, 4, calls=2)  # carried state
     run_case(ref_model, "e2e_72x104_T3", 72, 104, 3)                     # odd sizes: 9x13 -> 5x7 -> 3x4
+    run_case(ref_model, "e2e_lstm_96x160_T4_two_calls", 96, 160, 4, calls=2, cls="UAVSAL_LSTM")
     run_case(ref_model, "e2e_288x512_T8", 288, 512, 8, tap_stride=211, state_stride=29)
     run_case(ref_model, "e2e_360x640_T8", 360, 640, 8, tap_stride=331, state_stride=47)
     run_convlstm(ref_rnn)

@@ -203,3 +203,23 @@ def test_predict_video_equals_manual_loop(hip_model, oracle):
     assert (maps.cpu() - ref_maps).abs().max().item() <= MAP_TOL["f32"]
     ref0 = post_ref.to_uint8(post_ref.postprocess_predictions(ref_maps[0, 0].numpy(), H, W))
     assert np.abs(sal[0].cpu().numpy().astype(np.int32) - ref0.astype(np.int32)).max() <= 2
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+def test_lstm_variant_vs_reference_golden_and_oracle(golden_dir, prec):
+    """UAVSAL_LSTM (reference model.py:960-1076): ConvLSTM recurrence, (h, c) carried across two calls."""
+    from iip_uavsal_saliency_amd import UAVSAL_LSTM
+    g = np.load(os.path.join(golden_dir, "e2e_lstm_96x160_T4_two_calls.npz"))
+    m = UAVSAL_LSTM(time_dims=4, precision=prec)
+    synth.load_synth_weights(m, int(g["seed"]))
+    m = m.cuda().eval()
+    state = None
+    for c in range(2):
+        x, cb = make_inputs(4, 96, 160, int(g["seed"]), t0=c * 4)
+        out, st = m(x.cuda(), [cb[0].cuda(), cb[1].cuda()], state)
+        state = [(st[0], st[1])]
+        sfx = "" if c == 0 else f"_call{c}"
+        assert np.abs(out.cpu().numpy() - g["out" + sfx]).max() <= MAP_TOL[prec]
+        ss = int(g["state_stride"])
+        assert np.abs(st[0].cpu().contiguous().view(-1).numpy()[::ss] - g["state" + sfx]).max() <= STATE_TOL[prec]
+        assert np.abs(st[1].cpu().contiguous().view(-1).numpy()[::ss] - g["cstate" + sfx]).max() <= STATE_TOL[prec]

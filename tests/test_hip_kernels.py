@@ -135,6 +135,31 @@ def test_twa_step(ops, prec):
     assert err <= TOL[prec] * 4.0, (prec, err)
 
 
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+def test_convlstm_step_vs_reference_golden(ops, prec, golden_dir):
+    """ConvLSTMCell.forward: the golden was produced by the reference's own model_convlstm.py."""
+    import os
+    from iip_uavsal_saliency_amd import synth
+    g = np.load(os.path.join(golden_dir, "convlstm_step.npz"))
+    hid, (h, w), seed = int(g["hid"]), g["hw"], int(g["seed"])
+    wgt = torch.from_numpy(synth.synth_tensor("convlstm.rnn_conv.weight", (4 * hid, 2 * hid, 3, 3), seed))
+    mk = lambda nm: torch.from_numpy(synth.hash_normal(nm, hid * h * w, seed).astype(np.float32)).view(1, hid, h, w)
+    x, hp, cp = mk("convlstm.x"), mk("convlstm.h"), mk("convlstm.c")
+    hn, cn = ops.lstm_step(nhwc(x), nhwc(hp), nhwc(cp), wgt, prec=prec)
+    assert np.abs(nchw(hn).numpy() - g["h_next"]).max() <= TOL[prec] * 4
+    assert np.abs(nchw(cn).numpy() - g["c_next"]).max() <= TOL[prec] * 4
+
+
+def test_convlstm_step_256(ops):
+    from oracle.uavsal_ref import convlstm_cell_step
+    n, c, h, w = 2, 256, 12, 20
+    x, hp, cp = rnd((n, c, h, w), 141), rnd((n, c, h, w), 142), rnd((n, c, h, w), 143)
+    wt = rnd((4 * c, 2 * c, 3, 3), 144, 1.0 / np.sqrt(9 * 2 * c))
+    rh, rc = convlstm_cell_step(wt, x, hp, cp)
+    hn, cn = ops.lstm_step(nhwc(x), nhwc(hp), nhwc(cp), wt)
+    assert (nchw(hn) - rh).abs().max().item() <= 1e-4 and (nchw(cn) - rc).abs().max().item() <= 1e-4
+
+
 DW_CASES = [
     # n, h, w, c, stride, dilation
     (2, 9, 13, 48, 1, 1), (1, 12, 20, 120, 1, 1), (2, 45, 80, 1536, 1, 1), (1, 23, 41, 96, 2, 1),

@@ -24,6 +24,21 @@ def _sub(t, stride):
     return t.contiguous().view(-1).numpy()[::stride]
 
 
+def test_oracle_lstm_matches_reference_golden(golden_dir):
+    """The ConvLSTM variant (reference UAVSAL_LSTM, model.py:960-1076) incl. the (h, c) state protocol."""
+    g = np.load(os.path.join(golden_dir, "e2e_lstm_96x160_T4_two_calls.npz"))
+    model = R.build_oracle(time_dims=4, seed=int(g["seed"]), rnn="lstm")
+    state = None
+    for c in range(2):
+        x, cb = make_inputs(4, 96, 160, int(g["seed"]), t0=c * 4)
+        out, st = model(x, cb, state)
+        state = [(st[0], st[1])]
+        sfx = "" if c == 0 else f"_call{c}"
+        np.testing.assert_allclose(out.numpy(), g["out" + sfx], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(_sub(st[0], int(g["state_stride"])), g["state" + sfx], rtol=0, atol=2e-5)
+        np.testing.assert_allclose(_sub(st[1], int(g["state_stride"])), g["cstate" + sfx], rtol=0, atol=2e-5)
+
+
 @pytest.mark.parametrize("name", CASES + BIG)
 def test_oracle_matches_reference_golden(name, golden_dir):
     g = np.load(os.path.join(golden_dir, name + ".npz"))
