@@ -37,6 +37,28 @@ PEAK_HBM_GBS = 8000.0
 DTYPE_NAME = {"f32": "f32", "f16x3": "f32 (3x f16 split MFMA, f32 accumulate)",
               "bf16x3": "f32 (3x bf16 split MFMA, f32 accumulate)", "bf16": "bf16"}
 TILE_NAME = {1: "128x128", 2: "128x64", 3: "128x32", 4: "64x64"}
+PREC_ID = {"f32": 0, "bf16x3": 1, "bf16": 2, "f16x3": 3}
+# template arguments of the kernel instance each (precision, tile) launches, as rocprofv3 prints them
+F32_INST = {1: "2, 2, 2, 2, %d, 3, 1", 2: "4, 1, 1, 2, %d, 4, 1", 3: "4, 1, 1, 1, %d, 4, 1", 4: "2, 2, 1, 1, %d, 3, 4"}
+H16_INST = {1: "%d, 2, 2, 2, 2, %d", 2: "%d, 4, 1, 1, 2, %d", 3: "%d, 4, 1, 1, 1, %d", 4: "%d, 2, 2, 1, 1, %d"}
+
+
+def kernel_symbol(prec, tile, taps):
+    if prec == "f32":
+        return "conv_gemm_f32_dma_kernel<%s>" % (F32_INST[tile] % taps)
+    return "conv_gemm_kernel<%s>" % (H16_INST[tile] % (PREC_ID[prec], taps))
+
+
+def measured_traffic(symbol, C, T, H, W, prec):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950
+    note, + WRITE_SIZE; profiles/r1_hbm_traffic_f32_c1.json, collected for configs[1] only)."""
+    if (C, T, H, W, prec) != (1, 8, 360, 640, "f32"):
+        return None
+    path = os.path.join(ROOT, "profiles", "r1_hbm_traffic_f32_c1.json")
+    if not os.path.exists(path):
+        return None
+    rec = json.load(open(path)).get(symbol)
+    return None if rec is None else round(rec["hbm_mb_per_launch"] * 1e6)
 
 
 def log(msg):
@@ -74,7 +96,9 @@ def kernel_rooflines(eng, prec, iters=5):
     for i, m in enumerate(eng.ops_meta):
         ms = eng.time_ops(i, i + 1, iters)
         if m["kind"].startswith("conv"):
-            key = "conv_gemm_kernel<%s,%s,taps=%d>" % (prec, TILE_NAME[m["tile"]], 9 if m["kind"] == "conv3" else 1)
+            key = kernel_symbol(prec, m["tile"], 9 if m["kind"] == "conv3" else 1)
+        elif m["kind"] == "dw":
+            key = "dw3x3_dilated_kernel" if m.get("dil", 1) != 1 else ("dw3x3_kernel<1, 4, 4>" if m.get("stride", 1) == 1 else "dw3x3_kernel<2, 2, 2>")
         else:
             key = m["kind"]
         if os.environ.get("UAVSAL_BENCH_OPS"):
@@ -96,7 +120,8 @@ def roofline_obj(name, g, prec):
         return {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                 "frac": round(ach / peak, 4), "traffic": None, "launches_per_step": g["launches"],
                 "avg_launch_us": round(g["ms"] * 1e3 / g["launches"], 2),
-                "alg_gflop_per_launch": round(g["flops"] / g["launches"] / 1e9, 3)}
+                "alg_gflop_per_launch": round(g["flops"] / g["launches"] / 1e9, 3),
+                "alg_mb_per_launch": round(g["bytes"] / g["launches"] / 1e6, 3)}
     ach = g["bytes"] / sec / 1e9
     return {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
             "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None, "launches_per_step": g["launches"],
@@ -203,9 +228,12 @@ def main():
             dom = max(groups.items(), key=lambda kv: kv[1]["ms"])
             result["roofline"] = roofline_obj(dom[0], dom[1], args.prec)
             result["roofline"]["share_of_kernel_time"] = round(dom[1]["ms"] / tot, 3)
-            if "dw" in groups:
-                result["roofline_dw"] = roofline_obj("dw3x3_kernel", groups["dw"], args.prec)
-                result["roofline_dw"]["share_of_kernel_time"] = round(groups["dw"]["ms"] / tot, 3)
+            result["roofline"]["traffic"] = measured_traffic(dom[0], C, T, H, W, args.prec)
+            dwk = "dw3x3_kernel<1, 4, 4>"
+            if dwk in groups:
+                result["roofline_dw"] = roofline_obj(dwk, groups[dwk], args.prec)
+                result["roofline_dw"]["share_of_kernel_time"] = round(groups[dwk]["ms"] / tot, 3)
+                result["roofline_dw"]["traffic"] = measured_traffic(dwk, C, T, H, W, args.prec)
             result["kernel_time_ms"] = {k: round(v["ms"], 4) for k, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])}
             result["stage_time_ms"] = {k: round(eng.time_ops(a, b, 5), 4) for k, (a, b) in eng.stage_ranges.items()}
         if not args.no_cpu_baseline:
