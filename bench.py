@@ -97,6 +97,8 @@ def kernel_rooflines(eng, prec, iters=5):
         ms = eng.time_ops(i, i + 1, iters)
         if m["kind"].startswith("conv"):
             key = kernel_symbol(prec, m["tile"], 9 if m["kind"] == "conv3" else 1)
+            if m.get("fused_dw"):
+                key = "conv_gemm_kernel<%s, true>" % (H16_INST[m["tile"]] % (PREC_ID[prec], 1))
         elif m["kind"] == "dw":
             key = "dw3x3_dilated_kernel" if m.get("dil", 1) != 1 else ("dw3x3_kernel<1, 4, 4>" if m.get("stride", 1) == 1 else "dw3x3_kernel<2, 2, 2>")
         else:
@@ -160,6 +162,7 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--prec", default="f32", choices=["f32", "f16x3", "bf16x3", "bf16"])
     ap.add_argument("--graph", type=int, default=1, help="replay the launch plan as one hipGraph")
+    ap.add_argument("--fuse-dw", type=int, default=-1, help="-1 engine default, 0/1 force the fused depthwise->projection GEMM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
@@ -189,6 +192,7 @@ def main():
     synth.load_synth_weights(model, 0)
     model = model.to(device).eval()
     model.use_graph = bool(args.graph)
+    model.fuse_dw = None if args.fuse_dw < 0 else bool(args.fuse_dw)
 
     x_cpu, cb_cpu = make_clips(C, T, H, W, seed=shard.first)       # this rank's clips
     x = x_cpu.to(device)
@@ -221,6 +225,7 @@ def main():
 
     if rank == 0 and world == 1:
         eng = model._engine(device, C, T, H, W, "clip", False, torch.float32)
+        result["config"]["fused_dw"] = bool(eng.fuse_dw)
         if not args.no_roofline:
             log("per-kernel hipEvent timing of %d launches" % len(eng.ops_meta))
             groups = kernel_rooflines(eng, args.prec)

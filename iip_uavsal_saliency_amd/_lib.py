@@ -32,7 +32,9 @@ class ConvDesc(C.Structure):
                 ("n_img", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
                 ("Cin", C.c_int32), ("Cout", C.c_int32), ("taps", C.c_int32),
                 ("prec", C.c_int32), ("act", C.c_int32), ("epi", C.c_int32), ("tile", C.c_int32),
-                ("out2", _f), ("ld2", C.c_int32)]
+                ("out2", _f), ("ld2", C.c_int32),
+                ("dw_w9c", _f), ("dw_scale", _f), ("dw_bias", _f),
+                ("dw_stride", C.c_int32), ("dw_Hin", C.c_int32), ("dw_Win", C.c_int32)]
 
 
 class DwDesc(C.Structure):
@@ -124,7 +126,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.uavsal_abi_version() != 2:
+    if lib.uavsal_abi_version() != 3:
         raise RuntimeError("libuavsal_hip.so ABI version mismatch")
     for i, t in enumerate(DESC_TYPES):
         if lib.uavsal_sizeof_desc(i) != C.sizeof(t):

@@ -41,6 +41,8 @@ struct ConvK {
     const float* res;
     const float* aux;
     float* out2;
+    const float* dw_w; const float* dw_s; const float* dw_b;   // fused depthwise producer (or null)
+    int dw_stride, Hin, Win;
     long long a_is, o_is, r_is, x_is;
     int lda, ldc, ldr, ldx, ld2;
     int M, HW, H, W, Cin, Cout, Kpad, Npad, ktiles, act, epi;
@@ -211,9 +213,12 @@ __device__ __forceinline__ f32x4 prescale(f32x4 x) {
         }                                                                                            \
     }
 
-template <int PREC, int WAVES_M, int WAVES_N, int WM, int WN, int TAPS>
+// FUSE = true: the A operand is produced on the fly as relu6(bn(depthwise3x3(E))) from the expanded
+// tensor E (the `D` tensor of an inverted-residual block never exists in HBM): TAPS must be 1.
+template <int PREC, int WAVES_M, int WAVES_N, int WM, int WN, int TAPS, bool FUSE = false>
 __global__ __launch_bounds__(256, (WM * WN >= 4) ? ((PREC == UAVSAL_PREC_BF16X3 || PREC == UAVSAL_PREC_F16X3) ? 2 : 3) : 4)
 void conv_gemm_kernel(const ConvK p) {
+    static_assert(!FUSE || TAPS == 1, "the fused depthwise producer feeds a 1x1 projection");
     constexpr int BM = WAVES_M * WM * 32;
     constexpr int BN = WAVES_N * WN * 32;
     constexpr int KT = (PREC == UAVSAL_PREC_F32) ? 16 : 32;
@@ -259,7 +264,7 @@ void conv_gemm_kernel(const ConvK p) {
             const int m = m0 + row;
             a_ok[it] = m < p.M;
             const int mm = a_ok[it] ? m : 0;
-            if (TAPS == 1) {
+            if (TAPS == 1 && !FUSE) {
                 a_base[it] = row_off(mm, p.HW, p.a_is, p.contig) * p.lda;
                 a_y[it] = 0; a_x[it] = 0;
             } else {
@@ -288,6 +293,43 @@ void conv_gemm_kernel(const ConvK p) {
         }
         lt_ci += KT;
         if (TAPS == 9 && lt_ci >= p.Cin) { lt_ci = 0; ++lt_tap; }
+        if (FUSE) {
+            // depthwise 3x3 (+BN+ReLU6) of E for this thread's rows and 4-channel groups
+#pragma unroll
+            for (int l = 0; l < NLD; ++l) {
+                const int kk = ci0 + ch * 4 + l * 16;
+                const bool kin = kk < p.Cin;
+                const int kc = kin ? kk : 0;
+                f32x4 accd[A_IT];
+#pragma unroll
+                for (int it = 0; it < A_IT; ++it) accd[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const f32x4 wv = *reinterpret_cast<const f32x4*>(p.dw_w + (size_t)(ky * 3 + kx) * p.Cin + kc);
+#pragma unroll
+                        for (int it = 0; it < A_IT; ++it) {
+                            const int iy = a_y[it] * p.dw_stride - 1 + ky, ix = a_x[it] * p.dw_stride - 1 + kx;
+                            const bool ok = a_ok[it] && kin && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
+                            if (ok)
+                                accd[it] += *reinterpret_cast<const f32x4*>(
+                                    p.a + (a_base[it] + (long long)iy * p.Win + ix) * p.lda + kk) * wv;
+                        }
+                    }
+                }
+                const f32x4 sv = *reinterpret_cast<const f32x4*>(p.dw_s + kc);
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(p.dw_b + kc);
+#pragma unroll
+                for (int it = 0; it < A_IT; ++it) {
+                    f32x4 d = accd[it] * sv + bv;
+                    d.x = fminf(fmaxf(d.x, 0.f), 6.f); d.y = fminf(fmaxf(d.y, 0.f), 6.f);
+                    d.z = fminf(fmaxf(d.z, 0.f), 6.f); d.w = fminf(fmaxf(d.w, 0.f), 6.f);
+                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                    a_reg[it][l] = (a_ok[it] && kin) ? d : z;
+                }
+            }
+        } else {
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             bool ok = a_ok[it];
@@ -306,6 +348,7 @@ void conv_gemm_kernel(const ConvK p) {
                 f32x4 z = {0.f, 0.f, 0.f, 0.f};
                 a_reg[it][l] = okk ? *reinterpret_cast<const f32x4*>(p.a + off + kk) : z;
             }
+        }
         }
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
@@ -706,7 +749,11 @@ int launch_variant(const ConvK& k0, int taps, hipStream_t stream) {
     const int tiles_m = (k.M + BM - 1) / BM;
     k.tiles_n = (k.Cout + BN - 1) / BN;
     k.nblk = tiles_m * k.tiles_n;
-    if (taps == 1) {
+    if (taps == 1 && k.dw_w) {
+        static const int cap = resident_grid(conv_gemm_kernel<PREC, WAVES_M, WAVES_N, WM, WN, 1, true>, SMEM);
+        const int grid = k.nblk < cap ? k.nblk : cap;
+        hipLaunchKernelGGL((conv_gemm_kernel<PREC, WAVES_M, WAVES_N, WM, WN, 1, true>), dim3(grid), dim3(256), SMEM, stream, k);
+    } else if (taps == 1) {
         static const int cap = resident_grid(conv_gemm_kernel<PREC, WAVES_M, WAVES_N, WM, WN, 1>, SMEM);
         const int grid = k.nblk < cap ? k.nblk : cap;
         hipLaunchKernelGGL((conv_gemm_kernel<PREC, WAVES_M, WAVES_N, WM, WN, 1>), dim3(grid), dim3(256), SMEM, stream, k);
@@ -808,11 +855,22 @@ extern "C" int uavsal_conv_gemm(const uavsal_conv_desc* d, uavsal_stream_t strea
     const long long HW = (long long)d->H * d->W;
     const long long M = HW * d->n_img;
     if (M > 0x7fffffffLL) return UAVSAL_ESHAPE;
-    if (d->a_img_stride < HW || d->o_img_stride < HW) return UAVSAL_ESHAPE;
+    if (d->dw_w9c) {     // fused depthwise producer
+        if (d->taps != 1 || d->epi != UAVSAL_EPI_AFFINE || !d->dw_scale || !d->dw_bias) return UAVSAL_ESHAPE;
+        if (d->dw_stride != 1 && d->dw_stride != 2) return UAVSAL_ESHAPE;
+        if ((d->dw_Hin - 1) / d->dw_stride + 1 != d->H || (d->dw_Win - 1) / d->dw_stride + 1 != d->W) return UAVSAL_ESHAPE;
+        if (d->a_img_stride < (long long)d->dw_Hin * d->dw_Win) return UAVSAL_ESHAPE;
+        if (!uavsal_aligned16(d->dw_w9c) || !uavsal_aligned16(d->dw_scale) || !uavsal_aligned16(d->dw_bias)) return UAVSAL_EALIGN;
+    } else if (d->a_img_stride < HW) {
+        return UAVSAL_ESHAPE;
+    }
+    if (d->o_img_stride < HW) return UAVSAL_ESHAPE;
 
     ConvK k;
     k.a = d->a; k.w = (const char*)d->w; k.scale = d->scale; k.bias = d->bias;
     k.out = d->out; k.res = d->res; k.aux = d->aux; k.out2 = d->out2; k.ld2 = d->ld2;
+    k.dw_w = d->dw_w9c; k.dw_s = d->dw_scale; k.dw_b = d->dw_bias;
+    k.dw_stride = d->dw_stride; k.Hin = d->dw_Hin; k.Win = d->dw_Win;
     k.a_is = d->a_img_stride; k.o_is = d->o_img_stride;
     k.r_is = d->res ? d->r_img_stride : HW; k.x_is = d->aux ? d->x_img_stride : HW;
     k.lda = d->lda; k.ldc = d->ldc; k.ldr = d->ldr; k.ldx = d->ldx;
@@ -822,13 +880,14 @@ extern "C" int uavsal_conv_gemm(const uavsal_conv_desc* d, uavsal_stream_t strea
     k.Npad = (d->Cout + 31) / 32 * 32;
     k.ktiles = k.Kpad / KT;
     k.act = d->act; k.epi = d->epi;
-    k.contig = (k.a_is == HW && k.o_is == HW && k.r_is == HW && k.x_is == HW) ? 1 : 0;
+    k.contig = ((k.a_is == HW || k.dw_w) && k.o_is == HW && k.r_is == HW && k.x_is == HW) ? 1 : 0;
     k.tiles_n = 0; k.nblk = 0;
     int tile = (d->tile >= 1 && d->tile <= 4) ? d->tile : pick_tile(M, d->Cout);
     if (d->epi == UAVSAL_EPI_LSTM) tile = 4;     // the LSTM update lives in the 64x64 tile's vector epilogue
     hipStream_t s = (hipStream_t)stream;
     switch (d->prec) {
-        case UAVSAL_PREC_F32: return launch_f32(k, d->taps, tile, s);
+        case UAVSAL_PREC_F32:    // the fused producer needs register staging: use the generic kernel
+            return k.dw_w ? launch_prec<UAVSAL_PREC_F32>(k, d->taps, tile, s) : launch_f32(k, d->taps, tile, s);
         case UAVSAL_PREC_BF16X3: return launch_prec<UAVSAL_PREC_BF16X3>(k, d->taps, tile, s);
         case UAVSAL_PREC_F16X3: return launch_prec<UAVSAL_PREC_F16X3>(k, d->taps, tile, s);
         default: return launch_prec<UAVSAL_PREC_BF16>(k, d->taps, tile, s);

@@ -144,5 +144,5 @@ extern "C" int uavsal_sizeof_desc(int which) {
 }
 
 extern "C" const char* uavsal_build_info(void) {
-    return "libuavsal_hip gfx950 abi " "2" " (" __DATE__ " " __TIME__ ")";
+    return "libuavsal_hip gfx950 abi " "3" " (" __DATE__ " " __TIME__ ")";
 }

@@ -52,7 +52,7 @@ class V:
 
 class Engine:
     def __init__(self, model, device, n_seq, seq_len, H, W, ctx_T, ctx_mode="tile",
-                 precision="f32", taps=False, in_dtype=torch.float32, use_graph=False):
+                 precision="f32", taps=False, in_dtype=torch.float32, use_graph=False, fuse_dw=None):
         if precision not in L.PREC:
             raise ValueError("precision must be one of %s" % list(L.PREC))
         self.lib = L.load()
@@ -67,6 +67,11 @@ class Engine:
         self.keep_taps = taps
         self.in_dtype = in_dtype
         self.use_graph = use_graph
+        # fused depthwise->projection GEMM (uavsal_conv_desc.dw_*): D never reaches HBM.
+        # Measured (profiles/README.md): as written -- nine dependent global loads per staged value, no
+        # LDS-staged halo tile -- the fused loader is latency-bound and ~1.5x SLOWER end to end, so it is
+        # off unless asked for; kept as a correct, tested building block for a later halo-staged version.
+        self.fuse_dw = False if fuse_dw is None else bool(fuse_dw)
         if self.N % ctx_T:
             raise RuntimeError("frame count %d is not a multiple of time_dims %d" % (self.N, ctx_T))
         self.h = _down(_down(_down(H)))
@@ -155,10 +160,15 @@ class Engine:
 
     def conv(self, name, a: V, conv, bn, out: V, act, taps=1, res: Optional[V] = None, wslice=None,
              epi=L.EPI_AFFINE, aux: Optional[V] = None, n_img=None, strides=None, cout=None,
-             out2: Optional[V] = None, gate_interleave=0):
+             out2: Optional[V] = None, gate_interleave=0, dw=None):
+        """`dw=(dw_conv, dw_bn, stride)`: `a` is the expanded tensor and the depthwise 3x3 + BN + ReLU6
+        is produced inside this GEMM's loader (uavsal_conv_desc.dw_*)."""
         cin = a.c
         cout = out.c if cout is None else cout
         n_img = a.n if n_img is None else n_img
+        hin, win = a.h, a.w
+        if dw is not None:
+            a = V(a.t, a.n, (hin - 1) // dw[2] + 1, (win - 1) // dw[2] + 1, a.c, a.ld, a.coff)
         hw = a.h * a.w
         flops = 2.0 * n_img * hw * cin * cout * taps
         byts = 4.0 * n_img * hw * (cin + cout) + 4.0 * cin * cout * taps
@@ -168,7 +178,16 @@ class Engine:
             return
         d = L.ConvDesc()
         st = strides or {}
-        d.a, d.lda, d.a_img_stride = a.ptr, a.ld, st.get("a", hw)
+        d.a, d.lda, d.a_img_stride = a.ptr, a.ld, st.get("a", hin * win if dw is not None else hw)
+        if dw is not None:
+            key = ("dw", id(dw[0]))
+            if key not in self._wcache:
+                s_, b_ = P.fold_bn(dw[1])
+                self._wcache[key] = (self._dev(P.pack_dw_weight(dw[0].weight)), self._dev(s_), self._dev(b_))
+            w9, s_, b_ = self._wcache[key]
+            d.dw_w9c, d.dw_scale, d.dw_bias = w9.data_ptr(), s_.data_ptr(), b_.data_ptr()
+            d.dw_stride, d.dw_Hin, d.dw_Win = dw[2], hin, win
+            self.ops_meta[-1]["fused_dw"] = True
         d.w = self._convw(conv, wslice, gate_interleave).data_ptr()
         if bn is not None:
             s, b = self._affine(bn, cout)
@@ -244,6 +263,11 @@ class Engine:
             e = x
             dwc, dwbn, pl, plbn = seq[0][0], seq[0][1], seq[1], seq[2]
         ho, wo = (x.h - 1) // stride + 1, (x.w - 1) // stride + 1
+        if self.fuse_dw and dil == 1 and blk.expand_ratio != 1:
+            # depthwise computed inside the projection GEMM's loader: D never reaches HBM
+            self.conv(name + ".dwpl", e, pl, plbn, out, final_act, res=x if blk.use_res_connect else None,
+                      dw=(dwc, dwbn, stride))
+            return
         dd = self._scr("D", x.n, ho, wo, blk.hidden)
         self.dw(name + ".dw", e, dwc, dwbn, dd, stride, dil)
         self.conv(name + ".pl", dd, pl, plbn, out, final_act, res=x if blk.use_res_connect else None)

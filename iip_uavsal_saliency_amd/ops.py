@@ -32,10 +32,14 @@ def _nhwc_view(t: torch.Tensor):
     return t.data_ptr(), ld, n, h, w, c
 
 
-def conv_gemm(x, weight, scale=None, bias=None, act=L.ACT_NONE, res=None, out=None, prec="f32", tile=0):
-    """Dense 1x1 / 3x3 conv (+ folded BN, activation, residual).  `weight` [Cout,Cin,k,k] (cpu or cuda)."""
+def conv_gemm(x, weight, scale=None, bias=None, act=L.ACT_NONE, res=None, out=None, prec="f32", tile=0, dw=None):
+    """Dense 1x1 / 3x3 conv (+ folded BN, activation, residual).  `weight` [Cout,Cin,k,k] (cpu or cuda).
+    `dw=(w[C,1,3,3], scale[C], bias[C], stride)`: x is the expanded tensor and the depthwise 3x3 + BN + ReLU6
+    in front of this 1x1 conv is computed inside the GEMM's loader (fused inverted-residual tail)."""
     lib = L.load()
-    ap, lda, n, h, w, cin = _nhwc_view(x)
+    ap, lda, n, hin, win, cin = _nhwc_view(x)
+    stride = dw[3] if dw is not None else 1
+    h, w = (hin - 1) // stride + 1, (win - 1) // stride + 1
     cout, taps = weight.shape[0], weight.shape[2] * weight.shape[3]
     if out is None:
         out = torch.empty((n, h, w, cout), dtype=torch.float32, device=x.device)
@@ -43,7 +47,13 @@ def conv_gemm(x, weight, scale=None, bias=None, act=L.ACT_NONE, res=None, out=No
     wp = P.pack_conv_weight(weight, prec).to(x.device)
     keep = [wp]
     d = L.ConvDesc()
-    d.a, d.lda, d.a_img_stride = ap, lda, h * w
+    d.a, d.lda, d.a_img_stride = ap, lda, hin * win
+    if dw is not None:
+        w9 = P.pack_dw_weight(dw[0]).to(x.device)
+        ds, db = dw[1].float().contiguous().to(x.device), dw[2].float().contiguous().to(x.device)
+        keep += [w9, ds, db]
+        d.dw_w9c, d.dw_scale, d.dw_bias = w9.data_ptr(), ds.data_ptr(), db.data_ptr()
+        d.dw_stride, d.dw_Hin, d.dw_Win = stride, hin, win
     d.w = wp.data_ptr()
     if scale is not None:
         npad = P.roundup(cout, 32)

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define UAVSAL_ABI_VERSION 2
+#define UAVSAL_ABI_VERSION 3
 
 /* argument errors */
 #define UAVSAL_EINVAL   (-1)  /* null pointer / non-positive size */
@@ -108,6 +108,14 @@ typedef struct uavsal_conv_desc {
     int32_t prec, act, epi;
     int32_t tile;                /* 0 = auto; else 1: 128x128, 2: 128x64, 3: 128x32, 4: 64x64 block tile */
     float*       out2;   int32_t ld2;                 /* EPI_LSTM only: c_t (image stride = o_img_stride) */
+    /* Fused depthwise producer (taps == 1, EPI_AFFINE): when dw_w9c != NULL, `a` is the EXPANDED tensor E
+     * [n_img, dw_Hin, dw_Win, Cin] of an inverted-residual block and the GEMM's A operand is computed on the
+     * fly as relu6(dw_scale * depthwise3x3(E; dw_w9c, stride dw_stride, pad 1) + dw_bias), i.e. the
+     * groups=hidden BasicConv2d of dwBlock (model.py:92) feeding its pw-linear conv (model.py:94) without the
+     * intermediate tensor ever reaching HBM.  H, W are the OUTPUT sizes ((dw_Hin-1)/dw_stride+1, ...);
+     * dw_w9c is tap-major [9][Cin] as in uavsal_dw_desc; a_img_stride counts input pixels. */
+    const float* dw_w9c; const float* dw_scale; const float* dw_bias;
+    int32_t dw_stride, dw_Hin, dw_Win;
 } uavsal_conv_desc;
 
 int uavsal_conv_gemm(const uavsal_conv_desc* d, uavsal_stream_t stream);

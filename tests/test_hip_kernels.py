@@ -160,6 +160,31 @@ def test_convlstm_step_256(ops):
     assert (nchw(hn) - rh).abs().max().item() <= 1e-4 and (nchw(cn) - rc).abs().max().item() <= 1e-4
 
 
+FUSED_CASES = [(2, 12, 20, 384, 64, 1, True), (1, 45, 80, 1536, 256, 1, False), (2, 23, 41, 96, 24, 2, False),
+               (1, 9, 13, 48, 64, 1, False), (2, 45, 80, 1152, 64, 1, False), (1, 45, 80, 192, 64, 2, False)]
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16x3", "bf16x3"])
+@pytest.mark.parametrize("case", FUSED_CASES)
+def test_fused_depthwise_projection(ops, prec, case):
+    """dw3x3+BN+ReLU6 -> 1x1+BN (+res) in one launch == the two reference convs of dwBlock (model.py:92-95)."""
+    n, h, w, c, cout, stride, use_res = case
+    e = rnd((n, c, h, w), 151, 3.0).clamp(0, 6)
+    wd = rnd((c, 1, 3, 3), 152, 0.4)
+    sd, bd = rnd((c,), 153) * 0.5 + 1.0, rnd((c,), 154)
+    wp = rnd((cout, c, 1, 1), 155, 1.0 / np.sqrt(c))
+    sp, bp = rnd((cout,), 156) * 0.5 + 1.0, rnd((cout,), 157)
+    dmid = torch.clamp(F.conv2d(e, wd, stride=stride, padding=1, groups=c) * sd.view(1, -1, 1, 1) + bd.view(1, -1, 1, 1), 0, 6)
+    ref = F.conv2d(dmid, wp) * sp.view(1, -1, 1, 1) + bp.view(1, -1, 1, 1)
+    res = rnd(tuple(ref.shape), 158) if use_res else None
+    if use_res:
+        ref = ref + res
+    got = ops.conv_gemm(nhwc(e), wp, sp, bp, res=nhwc(res) if use_res else None, prec=prec, dw=(wd, sd, bd, stride))
+    assert tuple(got.shape) == (n, ref.shape[2], ref.shape[3], cout)
+    err = (nchw(got) - ref).abs().max().item()
+    assert err <= TOL[prec] * 8.0, (case, prec, err)
+
+
 DW_CASES = [
     # n, h, w, c, stride, dilation
     (2, 9, 13, 48, 1, 1), (1, 12, 20, 120, 1, 1), (2, 45, 80, 1536, 1, 1), (1, 23, 41, 96, 2, 1),
