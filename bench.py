@@ -161,7 +161,9 @@ def main():
     ap.add_argument("--height", type=int, default=360)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--prec", default="f32", choices=["f32", "f16x3", "bf16x3", "bf16"])
-    ap.add_argument("--graph", type=int, default=1, help="replay the launch plan as one hipGraph")
+    ap.add_argument("--graph", type=int, default=0, help="1: replay the launch plan as one hipGraph (measured slower "
+                    "than the native launch loop on ROCm 7.2: 1227-1247 vs 1268-1288 frames/s)")
+    ap.add_argument("--lanes", type=int, default=1, help="run independent branches on parallel streams / graph branches")
     ap.add_argument("--fuse-dw", type=int, default=-1, help="-1 engine default, 0/1 force the fused depthwise->projection GEMM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -193,6 +195,7 @@ def main():
     model = model.to(device).eval()
     model.use_graph = bool(args.graph)
     model.fuse_dw = None if args.fuse_dw < 0 else bool(args.fuse_dw)
+    model.use_lanes = bool(args.lanes)
 
     x_cpu, cb_cpu = make_clips(C, T, H, W, seed=shard.first)       # this rank's clips
     x = x_cpu.to(device)

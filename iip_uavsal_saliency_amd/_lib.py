@@ -99,6 +99,10 @@ SYMBOLS = [
     ("uavsal_plan_add_tdiff", C.c_int, [C.c_void_p, C.POINTER(TdiffDesc)]),
     ("uavsal_plan_add_tsum", C.c_int, [C.c_void_p, C.POINTER(TsumDesc)]),
     ("uavsal_plan_add_layout", C.c_int, [C.c_void_p, C.POINTER(LayoutDesc)]),
+    ("uavsal_plan_set_lane", C.c_int, [C.c_void_p, C.c_int]),
+    ("uavsal_plan_add_fork", C.c_int, [C.c_void_p, C.c_int]),
+    ("uavsal_plan_add_join", C.c_int, [C.c_void_p, C.c_int]),
+    ("uavsal_plan_enable_lanes", C.c_int, [C.c_void_p, C.c_int]),
     ("uavsal_plan_size", C.c_int, [C.c_void_p]),
     ("uavsal_plan_run", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     ("uavsal_plan_graph_build", C.c_int, [C.c_void_p, C.c_void_p]),
@@ -126,7 +130,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.uavsal_abi_version() != 3:
+    if lib.uavsal_abi_version() != 4:
         raise RuntimeError("libuavsal_hip.so ABI version mismatch")
     for i, t in enumerate(DESC_TYPES):
         if lib.uavsal_sizeof_desc(i) != C.sizeof(t):

@@ -8,10 +8,17 @@
 #include "common.h"
 
 namespace {
-enum OpKind { OP_CONV = 0, OP_DW, OP_STEM, OP_BILINEAR, OP_TDIFF, OP_TSUM, OP_LAYOUT };
+enum OpKind { OP_CONV = 0, OP_DW, OP_STEM, OP_BILINEAR, OP_TDIFF, OP_TSUM, OP_LAYOUT, OP_FORK, OP_JOIN };
+constexpr int MAX_LANES = 8;
 
+// Lanes: lane 0 is the caller's stream; lanes 1..7 are private streams on which independent
+// branches of the forward (prior nets, ASPP branches, the temporal branch of an STBlock) run
+// concurrently with the main chain.  OP_FORK(l): lane l waits for everything recorded on lane 0 so
+// far; OP_JOIN(l): lane 0 waits for lane l.  Under stream capture the same event waits become
+// graph edges, so the captured hipGraph has parallel branches.
 struct Op {
     int kind;
+    int lane;
     union {
         uavsal_conv_desc conv;
         uavsal_dw_desc dw;
@@ -41,6 +48,10 @@ struct uavsal_plan {
     std::vector<Op> ops;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
+    int cur_lane = 0;
+    bool lanes_on = true;
+    hipStream_t side[MAX_LANES] = {};
+    std::vector<hipEvent_t> events;      // one per fork/join op, created on first use
 };
 
 extern "C" uavsal_plan* uavsal_plan_create(void) { return new (std::nothrow) uavsal_plan(); }
@@ -49,14 +60,39 @@ extern "C" void uavsal_plan_destroy(uavsal_plan* p) {
     if (!p) return;
     if (p->exec) hipGraphExecDestroy(p->exec);
     if (p->graph) hipGraphDestroy(p->graph);
+    for (hipEvent_t e : p->events) if (e) hipEventDestroy(e);
+    for (int i = 1; i < MAX_LANES; ++i) if (p->side[i]) hipStreamDestroy(p->side[i]);
     delete p;
 }
+
+extern "C" int uavsal_plan_set_lane(uavsal_plan* p, int lane) {
+    if (!p || lane < 0 || lane >= MAX_LANES) return UAVSAL_EINVAL;
+    p->cur_lane = lane;
+    return 0;
+}
+
+extern "C" int uavsal_plan_enable_lanes(uavsal_plan* p, int on) {
+    if (!p) return UAVSAL_EINVAL;
+    if (p->exec) return UAVSAL_ESTATE;
+    p->lanes_on = on != 0;
+    return 0;
+}
+
+static int add_sync(uavsal_plan* p, int kind, int lane) {
+    if (!p || lane < 1 || lane >= MAX_LANES) return UAVSAL_EINVAL;
+    if (p->exec) return UAVSAL_ESTATE;
+    Op op; op.kind = kind; op.lane = lane;
+    p->ops.push_back(op);
+    return (int)p->ops.size() - 1;
+}
+extern "C" int uavsal_plan_add_fork(uavsal_plan* p, int lane) { return add_sync(p, OP_FORK, lane); }
+extern "C" int uavsal_plan_add_join(uavsal_plan* p, int lane) { return add_sync(p, OP_JOIN, lane); }
 
 #define UAVSAL_ADD(fn, KIND, field, T)                                   \
     extern "C" int fn(uavsal_plan* p, const T* d) {                      \
         if (!p || !d) return UAVSAL_EINVAL;                              \
         if (p->exec) return UAVSAL_ESTATE;                               \
-        Op op; op.kind = KIND; op.u.field = *d;                          \
+        Op op; op.kind = KIND; op.lane = p->cur_lane; op.u.field = *d;   \
         p->ops.push_back(op);                                            \
         return (int)p->ops.size() - 1;                                   \
     }
@@ -75,8 +111,28 @@ extern "C" int uavsal_plan_run(uavsal_plan* p, int first, int last, uavsal_strea
     const int n = (int)p->ops.size();
     if (last < 0 || last > n) last = n;
     if (first < 0 || first > last) return UAVSAL_EINVAL;
+    // lanes are honoured only when the whole plan runs; a sub-range (per-op timing) is launched flat
+    const bool lanes = p->lanes_on && first == 0 && last == n;
+    hipStream_t main_s = (hipStream_t)stream;
+    if (p->events.size() < p->ops.size()) p->events.resize(p->ops.size(), nullptr);
     for (int i = first; i < last; ++i) {
-        const int e = run_op(p->ops[i], stream);
+        const Op& op = p->ops[i];
+        if (op.kind == OP_FORK || op.kind == OP_JOIN) {
+            if (!lanes) continue;
+            if (!p->side[op.lane] &&
+                hipStreamCreateWithFlags(&p->side[op.lane], hipStreamNonBlocking) != hipSuccess) return (int)hipGetLastError();
+            if (!p->events[i] &&
+                hipEventCreateWithFlags(&p->events[i], hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
+            hipStream_t from = op.kind == OP_FORK ? main_s : p->side[op.lane];
+            hipStream_t to = op.kind == OP_FORK ? p->side[op.lane] : main_s;
+            hipError_t e = hipEventRecord(p->events[i], from);
+            if (e == hipSuccess) e = hipStreamWaitEvent(to, p->events[i], 0);
+            if (e != hipSuccess) return (int)e;
+            continue;
+        }
+        uavsal_stream_t s = (lanes && op.lane > 0) ? (uavsal_stream_t)p->side[op.lane] : stream;
+        if (lanes && op.lane > 0 && !p->side[op.lane]) return UAVSAL_ESTATE;    // op on a lane that was never forked
+        const int e = run_op(op, s);
         if (e) return e;
     }
     return 0;
@@ -144,5 +200,5 @@ extern "C" int uavsal_sizeof_desc(int which) {
 }
 
 extern "C" const char* uavsal_build_info(void) {
-    return "libuavsal_hip gfx950 abi " "3" " (" __DATE__ " " __TIME__ ")";
+    return "libuavsal_hip gfx950 abi " "4" " (" __DATE__ " " __TIME__ ")";
 }

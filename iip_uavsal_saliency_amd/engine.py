@@ -52,7 +52,8 @@ class V:
 
 class Engine:
     def __init__(self, model, device, n_seq, seq_len, H, W, ctx_T, ctx_mode="tile",
-                 precision="f32", taps=False, in_dtype=torch.float32, use_graph=False, fuse_dw=None):
+                 precision="f32", taps=False, in_dtype=torch.float32, use_graph=False, fuse_dw=None,
+                 use_lanes=True):
         if precision not in L.PREC:
             raise ValueError("precision must be one of %s" % list(L.PREC))
         self.lib = L.load()
@@ -81,20 +82,24 @@ class Engine:
         self.ops_meta: List[dict] = []
         self.stage_ranges: Dict[str, tuple] = {}
         self.named: Dict[str, V] = {}
-        self._scratch_need = {"E": 0, "D": 0}
-        self._scratch: Dict[str, torch.Tensor] = {}
+        self._scratch_need: Dict[tuple, int] = {}
+        self._scratch: Dict[tuple, torch.Tensor] = {}
+        self._lane = 0
         self.plan = None
         # pass 1 sizes the shared scratch, pass 2 records the launches
         self._dry = True
         self._build()
         for k, need in self._scratch_need.items():
             self._scratch[k] = torch.empty(max(need, 4), dtype=torch.float32, device=self.device)
+        self._lane = 0
         self._dry = False
         self.ops_meta, self.stage_ranges, self.named = [], {}, {}
         self.plan = C.c_void_p(self.lib.uavsal_plan_create())
         if not self.plan:
             raise RuntimeError("uavsal_plan_create failed")
         self._build()
+        self.use_lanes = bool(use_lanes)
+        L.check(self.lib.uavsal_plan_enable_lanes(self.plan, 1 if self.use_lanes else 0), "plan_enable_lanes")
         self._graph_ready = False
 
     def __del__(self):
@@ -118,11 +123,38 @@ class Engine:
         return v
 
     def _scr(self, kind, n, h, w, c) -> V:
+        """Scratch for the expanded tensors of an inverted-residual block, one pool per (kind, lane):
+        blocks on the same lane run back to back and share it, concurrent lanes never do."""
         numel = n * h * w * c
+        key = (kind, self._lane)
         if self._dry:
-            self._scratch_need[kind] = max(self._scratch_need[kind], numel)
+            self._scratch_need[key] = max(self._scratch_need.get(key, 0), numel)
             return V(_Fake(), n, h, w, c)
-        return V(self._scratch[kind], n, h, w, c)
+        return V(self._scratch[key], n, h, w, c)
+
+    # ---- parallel branches (uavsal_plan lanes) -----------------------------------------
+    def fork(self, lane):
+        """Following ops (until `main()`) go to `lane`, which starts after everything recorded on
+        lane 0 so far."""
+        self._meta(kind="sync", name="fork%d" % lane, flops=0.0, bytes=0.0)
+        if not self._dry:
+            r = self.lib.uavsal_plan_add_fork(self.plan, lane)
+            if r < 0:
+                L.check(r, "plan_add_fork")
+            L.check(self.lib.uavsal_plan_set_lane(self.plan, lane), "plan_set_lane")
+        self._lane = lane
+
+    def main(self):
+        if not self._dry:
+            L.check(self.lib.uavsal_plan_set_lane(self.plan, 0), "plan_set_lane")
+        self._lane = 0
+
+    def join(self, lane):
+        self._meta(kind="sync", name="join%d" % lane, flops=0.0, bytes=0.0)
+        if not self._dry:
+            r = self.lib.uavsal_plan_add_join(self.plan, lane)
+            if r < 0:
+                L.check(r, "plan_add_join")
 
     def _dev(self, t: torch.Tensor) -> torch.Tensor:
         d = t.contiguous().to(self.device)
@@ -312,6 +344,22 @@ class Engine:
             self.layout("ob.in", self.cb1_in.data_ptr(), o0.ptr, N, 20, hw, 20, 1)
         self._mark("boundary_in", s0)
 
+        # ---- gaussian / observed prior nets (model.py:349,352): they depend only on the caller's priors,
+        #      so they run on lanes 1 and 2 next to the backbone and are joined before fucb_layer
+        s0 = len(self.ops_meta)
+        cb = self._buf("cb192", N, h, w, 192)
+        g1 = self._buf("gauss1", N, h, w, 64)
+        o1 = self._buf("ob1", N, h, w, 64)
+        self.fork(1)
+        self.ir_block("gauss.0", g0, m.gauss_cb_layer[0], g1)
+        self.ir_block("gauss.1", g1, m.gauss_cb_layer[1], cb.slice(0, 64))
+        self.main()
+        self.fork(2)
+        self.ir_block("ob.0", o0, m.ob_cb_layer[0], o1)
+        self.ir_block("ob.1", o1, m.ob_cb_layer[1], cb.slice(64, 64))
+        self.main()
+        self._mark("priors_side", s0)
+
         # ---- backbone: MobileNetV2 features[0:18] (model_feature.py:62-69)
         s0 = len(self.ops_meta)
         H1, W1 = _down(self.H), _down(self.W)
@@ -349,18 +397,32 @@ class Engine:
         s0 = len(self.ops_meta)
         sf = m.sfnet
         aspp = self._buf("aspp", N, c5.h, c5.w, 1024)
-        self.conv("aspp1", c5, sf.lv5_aspp1[0], sf.lv5_aspp1[1], aspp.slice(0, 256), R6)
-        self.ir_block("aspp2", c5, sf.lv5_aspp2, aspp.slice(256, 256))
-        self.ir_block("aspp3", c5, sf.lv5_aspp3, aspp.slice(512, 256))
-        self.ir_block("aspp4", c5, sf.lv5_aspp4, aspp.slice(768, 256))
+        # the four ASPP branches and the two lateral convs are independent small launches on the
+        # 1/32 and 1/16 scale maps: spread them over lanes so they fill the chip together
         x5 = self._buf("x5", N, c5.h, c5.w, 256)
-        self.conv("conv_lv5", aspp, sf.conv_lv5[0], sf.conv_lv5[1], x5, R6)
         x4 = self._buf("x4", N, c4.h, c4.w, 128)
-        self.conv("conv_lv4", c4, sf.conv_lv4[0], sf.conv_lv4[1], x4, R6)
         cat = self._buf("srf_cat", N, h, w, 448)
-        self.bilinear("up_c5", x5, cat.slice(0, 256))
+        self.fork(3)
+        self.ir_block("aspp2", c5, sf.lv5_aspp2, aspp.slice(256, 256))
+        self.main()
+        self.fork(4)
+        self.ir_block("aspp3", c5, sf.lv5_aspp3, aspp.slice(512, 256))
+        self.main()
+        self.fork(5)
+        self.ir_block("aspp4", c5, sf.lv5_aspp4, aspp.slice(768, 256))
+        self.main()
+        self.fork(6)
+        self.conv("conv_lv4", c4, sf.conv_lv4[0], sf.conv_lv4[1], x4, R6)
         self.bilinear("up_c4", x4, cat.slice(256, 128))
         self.conv("conv_lv3", c3, sf.conv_lv3[0], sf.conv_lv3[1], cat.slice(384, 64), R6)
+        self.main()
+        self.conv("aspp1", c5, sf.lv5_aspp1[0], sf.lv5_aspp1[1], aspp.slice(0, 256), R6)
+        self.join(3)
+        self.join(4)
+        self.join(5)
+        self.conv("conv_lv5", aspp, sf.conv_lv5[0], sf.conv_lv5[1], x5, R6)
+        self.bilinear("up_c5", x5, cat.slice(0, 256))
+        self.join(6)
         x = self._buf("sfnet", N, h, w, 256)
         self.conv("conv_last", cat, sf.conv_last[0], sf.conv_last[1], x, R6, taps=9)
         self._mark("srf_head", s0)
@@ -369,19 +431,23 @@ class Engine:
         s0 = len(self.ops_meta)
         for i, st in enumerate(m.st_layer):
             sp = self._buf("st%d_sp" % i, N, h, w, 256)
-            self.ir_block("st%d.sp" % i, x, st.stconv_sp.spconv, sp)
             te = st.stconv_te
             r = self._buf("st%d_red" % i, N, h, w, 32)
-            self.conv("st%d.reduce" % i, x, te.reduce_conv[0], te.reduce_conv[1], r, R6)
             dif = self._buf("st%d_dif" % i, N, h, w, 64)
+            t1 = self._buf("st%d_te1" % i, N, h, w, 32)
+            # temporal branch (small launches) on lane 6, next to the spatial branch's big GEMMs
+            self.fork(6)
+            self.conv("st%d.reduce" % i, x, te.reduce_conv[0], te.reduce_conv[1], r, R6)
             self._meta(kind="tdiff", name="st%d.tdiff" % i, flops=0.0, bytes=4.0 * N * hw * 96)
             if not self._dry:
                 d = L.TdiffDesc()
                 d.inp, d.ldi, d.out, d.ldo = r.ptr, 32, dif.ptr, 64
                 d.n_img, d.HW, d.C, d.seq_len = N, hw, 32, self.seq_len
                 self._add(self.lib.uavsal_plan_add_tdiff, d, "plan_add_tdiff")
-            t1 = self._buf("st%d_te1" % i, N, h, w, 32)
             self.ir_block("st%d.sub" % i, dif, te.sub_conv, t1)
+            self.main()
+            self.ir_block("st%d.sp" % i, x, st.stconv_sp.spconv, sp)
+            self.join(6)
             ssum = self._buf("st%d_sum" % i, N, h, w, 256)
             self.conv("st%d.te_last" % i, t1, te.last_conv[0], te.last_conv[1], ssum, R6, res=sp)   # x_sp + x_te
             y = self._buf("st%d" % i, N, h, w, 256)
@@ -394,13 +460,6 @@ class Engine:
         fu = self._buf("fu320", N, h, w, 320)
         xs = fu.slice(0, 256)
         self.ir_block("fust", x, m.fust_layer[0], xs)
-        cb = self._buf("cb192", N, h, w, 192)
-        g1 = self._buf("gauss1", N, h, w, 64)
-        self.ir_block("gauss.0", g0, m.gauss_cb_layer[0], g1)
-        self.ir_block("gauss.1", g1, m.gauss_cb_layer[1], cb.slice(0, 64))
-        o1 = self._buf("ob1", N, h, w, 64)
-        self.ir_block("ob.0", o0, m.ob_cb_layer[0], o1)
-        self.ir_block("ob.1", o1, m.ob_cb_layer[1], cb.slice(64, 64))
         B = N // self.ctx_T
         tsum = self._buf("ctx_sum", B, h, w, 256)
         self._meta(kind="tsum", name="ctx.sum", flops=0.0, bytes=4.0 * (N + B) * hw * 256)
@@ -419,6 +478,8 @@ class Engine:
             self.bilinear("ctx.up", cx2, cb.slice(128, 64), src_mod=B, src_div=1)
         else:                            # independent clips: frame (c,t) <- clip c
             self.bilinear("ctx.up", cx2, cb.slice(128, 64), src_mod=N, src_div=self.ctx_T)
+        self.join(1)
+        self.join(2)
         self.ir_block("fucb", cb, m.fucb_layer[0], fu.slice(256, 64))
         self.named["fust_in_cb"] = fu.slice(256, 64)
         xf = self._buf("prefuse", N, h, w, 256)

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define UAVSAL_ABI_VERSION 3
+#define UAVSAL_ABI_VERSION 4
 
 /* argument errors */
 #define UAVSAL_EINVAL   (-1)  /* null pointer / non-positive size */
@@ -237,6 +237,14 @@ int uavsal_plan_add_bilinear(uavsal_plan* p, const uavsal_bilinear_desc* d);
 int uavsal_plan_add_tdiff(uavsal_plan* p, const uavsal_tdiff_desc* d);
 int uavsal_plan_add_tsum(uavsal_plan* p, const uavsal_tsum_desc* d);
 int uavsal_plan_add_layout(uavsal_plan* p, const uavsal_layout_desc* d);
+/* Parallel branches: ops are recorded on the current lane (0 = the caller's stream, 1..7 = private
+ * streams).  fork(l): lane l starts after everything recorded on lane 0 so far; join(l): lane 0 waits
+ * for lane l.  Every forked lane must be joined before the plan ends.  A captured plan keeps the
+ * branches as parallel graph nodes.  enable_lanes(0) runs everything on the caller's stream. */
+int uavsal_plan_set_lane(uavsal_plan* p, int lane);
+int uavsal_plan_add_fork(uavsal_plan* p, int lane);
+int uavsal_plan_add_join(uavsal_plan* p, int lane);
+int uavsal_plan_enable_lanes(uavsal_plan* p, int on);
 int uavsal_plan_size(const uavsal_plan* p);
 /* launch ops [first, last) in order on `stream` (last < 0: to the end) */
 int uavsal_plan_run(uavsal_plan* p, int first, int last, uavsal_stream_t stream);
