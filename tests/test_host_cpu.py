@@ -249,3 +249,23 @@ def test_reference_style_whole_model_pickle_loads_through_the_shim(tmp_path):
     load_reference_checkpoint(dst, path)
     for k, v in src.state_dict().items():
         assert torch.equal(v, dst.state_dict()[k]), k
+
+
+def test_mat_reader_and_priors(golden_dir):
+    """The minimal HDF5 reader against the reference's own prior files (when present) and the
+    converted fixtures; the closed-form gaussian priors equal the shipped gauss_priors.mat exactly."""
+    from iip_uavsal_saliency_amd import matio, priors
+    g_fix = np.load(os.path.join(golden_dir, "gauss_priors.npz"))["PriorMaps"]
+    closed = synth.gauss_priors(1, 45, 80)[0].transpose(1, 2, 0)
+    assert g_fix.shape == (45, 80, 8) and np.array_equal(closed, g_fix)
+    ref_dir = "/root/reference"
+    if os.path.isdir(ref_dir):
+        for name in ("gauss_priors", "UAV2_ob_priors_train", "AVS1K_ob_priors_train"):
+            a = matio.loadmat(os.path.join(ref_dir, name + ".mat"))["PriorMaps"]
+            assert np.array_equal(a, np.load(os.path.join(golden_dir, name + ".npz"))["PriorMaps"])
+    cb = priors.get_bias([1, 1, 1], 3, 45, 80, ob_prior_path=os.path.join(golden_dir, "UAV2_ob_priors_train.npz"),
+                         device="cpu")
+    assert tuple(cb[0].shape) == (3, 8, 45, 80) and tuple(cb[1].shape) == (3, 20, 45, 80)
+    assert cb[0].dtype == torch.float32 and float(cb[1].max()) <= 1.0
+    with pytest.raises(NotImplementedError):          # the cv2 uint8 letterbox quirk is not reproduced
+        priors.get_ob_priors(os.path.join(golden_dir, "UAV2_ob_priors_train.npz"), 1, 36, 64)
