@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "libuavsal_hip.so")
+LIB_PATH = os.environ.get("UAVSAL_HIP_LIB") or os.path.join(PKG, "libuavsal_hip.so")   # override: A/B builds
 
 PREC = {"f32": 0, "bf16x3": 1, "bf16": 2, "f16x3": 3}
 ACT_NONE, ACT_RELU6, ACT_SIGMOID = 0, 1, 2
