@@ -7,14 +7,15 @@
 // model.py:65-72, 94-95, 100-101) and ConvTWACell.forward (model_convlstm.py:276-292);
 // see include/uavsal_hip.h for the contract.
 //
-// Structure (one 256-thread workgroup = 4 wave64):
+// Structure (one 256-thread workgroup = 4 wave64; 8 waves for the split-16-bit 128 x 256 tile):
 //   * block tile BM x BN, K tile KT (16 fp32 or 32 bf16 elements = one 64-byte row of a
 //     panel).  A "panel" is rows x 64 B in LDS; a row holds four 16-byte chunks, chunk c
 //     stored at slot c ^ ((row >> 2) & 3) so that the ds_read_b128 fragment reads of 32
 //     different rows are bank-conflict free (guide: LDS XOR swizzle, T2).
-//   * global -> registers -> LDS staging, double buffered: tile k+1's global loads are
-//     issued before tile k's MFMAs and written to the other LDS stage after them
-//     (issue-early / write-late, one barrier per K tile).
+//   * global -> registers -> LDS staging, double buffered: K step s+D's global loads are
+//     issued before step s's MFMAs and step s+1 is written to the other LDS stage after them
+//     (issue-early / write-late, one barrier per K step; the loader is one unconditional,
+//     branch-free sequence across output tiles so that the vmcnt waits stay counted).
 //   * fp32 activations are converted while staging: F32 keeps them, BF16 rounds to bf16,
 //     BF16X3 splits x = hi + lo (two bf16) and issues hi*hi + hi*lo + lo*hi, i.e. ~16
 //     mantissa bits at 3/16 of the fp32-MFMA cost.
@@ -140,8 +141,8 @@ __device__ __forceinline__ f32x4 prescale(f32x4 x) {
                     }                                                                                \
                 }                                                                                    \
                 __syncthreads();                                                                     \
-                _Pragma("unroll") for (int it = 0; it < (32 * BN / 4 + 255) / 256; ++it) {           \
-                    const int idx = tid + it * 256;                                                  \
+                _Pragma("unroll") for (int it = 0; it < (32 * BN / 4 + NT - 1) / NT; ++it) {         \
+                    const int idx = tid + it * NT;                                                   \
                     const int row = idx / (BN / 4), c4 = idx - row * (BN / 4);                       \
                     const int gm = m0c + pp * 32 + row, gn = n0c + c4 * 4;                           \
                     if (row < 32 && gm < p.M && gn < p.Cout) {                                       \
@@ -213,24 +214,34 @@ __device__ __forceinline__ f32x4 prescale(f32x4 x) {
         }                                                                                            \
     }
 
+// 16 bytes of zeros: what out-of-range lanes (M / K tails, 3x3 zero padding) fetch instead of
+// being masked off
+__device__ __attribute__((aligned(16))) float g_zero16[4];
+
+#ifndef UAVSAL_GEMM_PREFETCH
+#define UAVSAL_GEMM_PREFETCH 2
+#endif
+
 // FUSE = true: the A operand is produced on the fly as relu6(bn(depthwise3x3(E))) from the expanded
 // tensor E (the `D` tensor of an inverted-residual block never exists in HBM): TAPS must be 1.
 template <int PREC, int WAVES_M, int WAVES_N, int WM, int WN, int TAPS, bool FUSE = false>
-__global__ __launch_bounds__(256, (WM * WN >= 4) ? ((PREC == UAVSAL_PREC_BF16X3 || PREC == UAVSAL_PREC_F16X3) ? 2 : 3) : 4)
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64,
+                             (WM * WN >= 4) ? ((PREC == UAVSAL_PREC_BF16X3 || PREC == UAVSAL_PREC_F16X3 || WAVES_M * WAVES_N == 8) ? 2 : 3) : 4)
 void conv_gemm_kernel(const ConvK p) {
+    constexpr int NT = WAVES_M * WAVES_N * 64;     // 4 waves, or 8 for the 128 x 256 tile
     static_assert(!FUSE || TAPS == 1, "the fused depthwise producer feeds a 1x1 projection");
     constexpr int BM = WAVES_M * WM * 32;
     constexpr int BN = WAVES_N * WN * 32;
     constexpr int KT = (PREC == UAVSAL_PREC_F32) ? 16 : 32;
     constexpr int NPAN = (PREC == UAVSAL_PREC_BF16X3 || PREC == UAVSAL_PREC_F16X3) ? 2 : 1;
     constexpr int NLD = (PREC == UAVSAL_PREC_F32) ? 1 : 2;   // float4 loads per A chunk
-    constexpr int A_IT = (BM * 4) / 256;
-    constexpr int B_IT = (BN * 4 + 255) / 256;
+    constexpr int A_IT = (BM * 4) / NT;
+    constexpr int B_IT = (BN * 4 + NT - 1) / NT;
     constexpr int APAN = BM * 64;
     constexpr int BPAN = BN * 64;
     constexpr int STAGE = NPAN * (APAN + BPAN);
-    static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
-    static_assert((BM * 4) % 256 == 0, "A tile must divide over 256 threads");
+    static_assert(NT == 256 || NT == 512, "4 or 8 waves per workgroup");
+    static_assert((BM * 4) % NT == 0, "A tile must divide over the workgroup's threads");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -260,7 +271,7 @@ void conv_gemm_kernel(const ConvK p) {
         n0 = tile_n * BN;
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
-            const int row = (tid >> 2) + it * 64;
+            const int row = (tid >> 2) + it * (NT / 4);
             const int m = m0 + row;
             a_ok[it] = m < p.M;
             const int mm = a_ok[it] ? m : 0;
@@ -277,22 +288,27 @@ void conv_gemm_kernel(const ConvK p) {
         }
     };
     const int b_row0 = tid >> 2;
+    // opaque to the optimiser: with a known global on one arm it turns `*(ok ? p : zero)` back into
+    // a divergent branch around two loads
+    size_t zero_page = (size_t)g_zero16;
+    asm volatile("" : "+s"(zero_page));
 
-    f32x4 a_reg[A_IT][NLD];
-    u32x4 b_reg[B_IT][NPAN];
+    // D register sets: K step s+D is requested while step s is multiplied.  Measured on the path's
+    // shapes (profiles/r1_gemm_probe_v3.log) the depth barely matters -- these kernels are bound by
+    // the conversion VALU work and the barrier-phased MFMA / VALU alternation, not by load latency:
+    // D = 1, 2, 3 are within 3% on the 4-wave tiles (1 is best and cheapest in registers); only the
+    // 8-wave 128 x 256 tile, alone on its CU, gains from D = 2 (up to 9% on the 64-frame expands).
+    constexpr int D = (!FUSE && WAVES_M * WAVES_N == 8) ? UAVSAL_GEMM_PREFETCH : 1;
+    f32x4 a_reg[D][A_IT][NLD];
+    u32x4 b_reg[D][B_IT][NPAN];
 
-    int lt_tap = 0, lt_ci = 0;                   // running K position (tiles are loaded in order)
-    auto load_tile = [&](int kt) {
-        if (kt == 0) { lt_tap = 0; lt_ci = 0; }
-        const int ci0 = lt_ci;
+    auto load_tile = [&](int kt, int ci0, int tap, int set) {
         int dy = 0, dx = 0;
         if (TAPS == 9) {
-            const int ty = (lt_tap * 11) >> 5;              // tap / 3 for tap in 0..9
+            const int ty = (tap * 11) >> 5;                 // tap / 3 for tap in 0..9
             dy = ty - 1;
-            dx = lt_tap - ty * 3 - 1;
+            dx = tap - ty * 3 - 1;
         }
-        lt_ci += KT;
-        if (TAPS == 9 && lt_ci >= p.Cin) { lt_ci = 0; ++lt_tap; }
         if (FUSE) {
             // depthwise 3x3 (+BN+ReLU6) of E for this thread's rows and 4-channel groups
 #pragma unroll
@@ -326,7 +342,7 @@ void conv_gemm_kernel(const ConvK p) {
                     d.x = fminf(fmaxf(d.x, 0.f), 6.f); d.y = fminf(fmaxf(d.y, 0.f), 6.f);
                     d.z = fminf(fmaxf(d.z, 0.f), 6.f); d.w = fminf(fmaxf(d.w, 0.f), 6.f);
                     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                    a_reg[it][l] = (a_ok[it] && kin) ? d : z;
+                    a_reg[set][it][l] = (a_ok[it] && kin) ? d : z;
                 }
             }
         } else {
@@ -344,41 +360,40 @@ void conv_gemm_kernel(const ConvK p) {
 #pragma unroll
             for (int l = 0; l < NLD; ++l) {
                 const int kk = ci0 + ch * 4 + l * 16;
+                // out-of-range lanes read the zero page: an unconditional load keeps the loop free of
+                // divergent branches, so the compiler can count vmcnt instead of draining to 0
                 const bool okk = ok && kk < p.Cin;
-                f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                a_reg[it][l] = okk ? *reinterpret_cast<const f32x4*>(p.a + off + kk) : z;
+                a_reg[set][it][l] = *(const __attribute__((address_space(1))) f32x4*)(
+                    okk ? (size_t)(p.a + off + kk) : zero_page);
             }
         }
         }
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
-            const int row = b_row0 + it * 64;
-            const int nn = n0 + row;
-            const bool ok = (row < BN) && (nn < p.Npad);
+            const int row = b_row0 + it * (NT / 4);
+            // rows past the padded weight matrix are clamped, not zeroed: they only feed output
+            // columns >= Cout, which the epilogue never stores (and a clamp keeps the load branch-free)
+            const int nn = min(n0 + row, p.Npad - 1);
 #pragma unroll
             for (int pn = 0; pn < NPAN; ++pn) {
-                u32x4 z = {0u, 0u, 0u, 0u};
-                if (ok) {
-                    const size_t esz = (PREC == UAVSAL_PREC_F32) ? 4 : 2;
-                    const size_t elem = ((size_t)pn * p.Npad + nn) * p.Kpad + (size_t)kt * KT;
-                    z = *reinterpret_cast<const u32x4*>(p.w + elem * esz + ch * 16);
-                }
-                b_reg[it][pn] = z;
+                const size_t esz = (PREC == UAVSAL_PREC_F32) ? 4 : 2;
+                const size_t elem = ((size_t)pn * p.Npad + nn) * p.Kpad + (size_t)kt * KT;
+                b_reg[set][it][pn] = *reinterpret_cast<const u32x4*>(p.w + elem * esz + ch * 16);
             }
         }
     };
 
-    auto store_tile = [&](int stage) {
+    auto store_tile = [&](int set, int stage) {
         char* As = smem + stage * STAGE;
         char* Bs = As + NPAN * APAN;
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
-            const int row = (tid >> 2) + it * 64;
+            const int row = (tid >> 2) + it * (NT / 4);
             const int slot = (row * 4 + (ch ^ ((row >> 2) & 3))) * 16;
             if (PREC == UAVSAL_PREC_F32) {
-                *reinterpret_cast<f32x4*>(As + slot) = a_reg[it][0];
+                *reinterpret_cast<f32x4*>(As + slot) = a_reg[set][it][0];
             } else {
-                const f32x4 x0 = prescale<PREC>(a_reg[it][0]), x1 = prescale<PREC>(a_reg[it][NLD - 1]);
+                const f32x4 x0 = prescale<PREC>(a_reg[set][it][0]), x1 = prescale<PREC>(a_reg[set][it][NLD - 1]);
                 u32x4 hi;
                 hi.x = pack2<PREC>(x0.x, x0.y); hi.y = pack2<PREC>(x0.z, x0.w);
                 hi.z = pack2<PREC>(x1.x, x1.y); hi.w = pack2<PREC>(x1.z, x1.w);
@@ -395,12 +410,12 @@ void conv_gemm_kernel(const ConvK p) {
         }
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
-            const int row = b_row0 + it * 64;
-            if (row < BN) {
+            const int row = b_row0 + it * (NT / 4);
+            if ((BN * 4) % NT == 0 || row < BN) {
                 const int slot = (row * 4 + (ch ^ ((row >> 2) & 3))) * 16;
 #pragma unroll
                 for (int pn = 0; pn < NPAN; ++pn)
-                    *reinterpret_cast<u32x4*>(Bs + pn * BPAN + slot) = b_reg[it][pn];
+                    *reinterpret_cast<u32x4*>(Bs + pn * BPAN + slot) = b_reg[set][it][pn];
             }
         }
     };
@@ -468,11 +483,40 @@ void conv_gemm_kernel(const ConvK p) {
         }
     };
 
+    // ---- the loader: one flat sequence of (output tile, K step) positions ---------------------
+    // It runs D positions ahead of the MFMAs and crosses output-tile boundaries, so the first K
+    // tiles of the next output tile land while the current tile's epilogue runs.  Every output tile
+    // takes S = roundup(ktiles, D) steps (the pad steps re-request the last K tile and multiply
+    // nothing), so a tile always starts in register set 0.  EVERY step issues the same number of
+    // loads, unconditionally: with a load behind a branch -- even a uniform one -- the compiler's
+    // waitcnt pass merges the two paths and waits for vmcnt(0), which is prefetch distance 1 again.
+    const int S = (p.ktiles + D - 1) / D * D;
+    int l_tile = tile, l_s = 0;                  // loader position
+    int lt_tap = 0, lt_ci = 0;                   // its running K position (advanced in order)
+    int l_kt = 0, l_ci0 = 0, l_tapv = 0;         // what the last real step requested
+    setup_tile(l_tile);
+    auto loader_step = [&](int set) {
+        if (l_s < p.ktiles) {
+            l_kt = l_s; l_ci0 = lt_ci; l_tapv = lt_tap;
+            lt_ci += KT;
+            if (TAPS == 9 && lt_ci >= p.Cin) { lt_ci = 0; ++lt_tap; }
+        }
+        load_tile(l_kt, l_ci0, l_tapv, set);
+        if (++l_s == S) {
+            l_s = 0; lt_ci = 0; lt_tap = 0;
+            if (l_tile + 1 < tile_end) {         // past the last tile: keep re-requesting it (harmless)
+                ++l_tile;
+                setup_tile(l_tile);
+            }
+        }
+    };
+
     // ---- persistent loop over this workgroup's output tiles -------------------------------
-    setup_tile(tile);
-    load_tile(0);
+#pragma unroll
+    for (int d = 0; d < D; ++d) loader_step(d);
     while (true) {
-        const int m0c = m0, n0c = n0;          // coordinates of the tile being computed
+        const int tile_m = tile / p.tiles_n;
+        const int m0c = tile_m * BM, n0c = (tile - tile_m * p.tiles_n) * BN;   // tile being computed
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -480,28 +524,26 @@ void conv_gemm_kernel(const ConvK p) {
 #pragma unroll
                 for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
 
-        store_tile(0);
+        store_tile(0, 0);
         __syncthreads();
-        for (int kt = 0; kt < p.ktiles; ++kt) {
-            const int cur = kt & 1;
-            const bool more = (kt + 1) < p.ktiles;
-            if (more) load_tile(kt + 1);
-            compute(cur);
-            if (more) store_tile(cur ^ 1);
-            __syncthreads();
-        }
-
-        // request the next tile's first K tile now; it lands while the epilogue runs
-        const bool has_next = (tile + 1) < tile_end;
-        if (has_next) {
-            ++tile;
-            setup_tile(tile);
-            load_tile(0);
+        for (int s0 = 0; s0 < S; s0 += D) {
+#pragma unroll
+            for (int u = 0; u < D; ++u) {          // K step s lives in register set s % D == u
+                const int st = s0 + u;
+                loader_step(u);                    // position st + D; set u went to LDS last step
+                // keep the order request -> multiply -> convert: hoisting the conversion of step
+                // st+1 above these requests would drain vmcnt first
+                if (D > 1) __builtin_amdgcn_sched_barrier(0);
+                if (st < p.ktiles) compute(st & 1);
+                if (D > 1) __builtin_amdgcn_sched_barrier(0);
+                if (st + 1 < p.ktiles) store_tile((u + 1) % D, (st + 1) & 1);
+                __syncthreads();
+            }
         }
 
         // ---- epilogue ------------------------------------------------------------------
         UAVSAL_GEMM_EPILOGUE((PREC == UAVSAL_PREC_F16X3 ? F16X3_ACC_SCALE : 1.0f), smem)
-        if (!has_next) break;
+        if (++tile >= tile_end) break;
     }
 }
 
@@ -521,13 +563,14 @@ void conv_gemm_kernel(const ConvK p) {
 // and therefore fetches logical chunk (l&3) ^ ((row>>2)&3)); fragment reads use the same XOR.
 // Out-of-range lanes (M / K tails, 3x3 zero padding) fetch from a 16-byte zero page instead of
 // being masked off (a masked lane would leave stale LDS behind).
-__device__ __attribute__((aligned(16))) float g_zero16[4];
+
 
 template <int WAVES_M, int WAVES_N, int WM, int WN, int TAPS, int S, int NKP>
 __global__ __launch_bounds__(256, (WM * WN >= 4) ? 3 : 4) void conv_gemm_f32_dma_kernel(const ConvK p) {
     constexpr int BM = WAVES_M * WM * 32;
     constexpr int BN = WAVES_N * WN * 32;
     constexpr int KT = 16;                       // one 64-byte panel row; a stage holds NKP panels
+    constexpr int NT = 256;
     constexpr int A_IT = (BM * 4) / 256;
     constexpr int B_IT = (BN * 4 + 255) / 256;
     constexpr int LPT = NKP * (A_IT + B_IT);     // DMA instructions per thread per stage
@@ -732,11 +775,11 @@ __global__ __launch_bounds__(256, (WM * WN >= 4) ? 3 : 4) void conv_gemm_f32_dma
 
 // resident workgroups per CU for one kernel instantiation (cached; queried once, outside any capture)
 template <typename K>
-int resident_grid(K kernel, int smem) {
+int resident_grid(K kernel, int smem, int threads = 256) {
     int per_cu = 0, cus = 0, dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 256;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, smem) != hipSuccess || per_cu <= 0) per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, smem) != hipSuccess || per_cu <= 0) per_cu = 1;
     return per_cu * cus;
 }
 
@@ -745,22 +788,23 @@ int launch_variant(const ConvK& k0, int taps, hipStream_t stream) {
     constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32;
     constexpr int NPAN = (PREC == UAVSAL_PREC_BF16X3 || PREC == UAVSAL_PREC_F16X3) ? 2 : 1;
     constexpr int SMEM = 2 * NPAN * (BM + BN) * 64;
+    constexpr int NT = WAVES_M * WAVES_N * 64;
     ConvK k = k0;
     const int tiles_m = (k.M + BM - 1) / BM;
     k.tiles_n = (k.Cout + BN - 1) / BN;
     k.nblk = tiles_m * k.tiles_n;
     if (taps == 1 && k.dw_w) {
-        static const int cap = resident_grid(conv_gemm_kernel<PREC, WAVES_M, WAVES_N, WM, WN, 1, true>, SMEM);
+        static const int cap = resident_grid(conv_gemm_kernel<PREC, WAVES_M, WAVES_N, WM, WN, 1, true>, SMEM, NT);
         const int grid = k.nblk < cap ? k.nblk : cap;
-        hipLaunchKernelGGL((conv_gemm_kernel<PREC, WAVES_M, WAVES_N, WM, WN, 1, true>), dim3(grid), dim3(256), SMEM, stream, k);
+        hipLaunchKernelGGL((conv_gemm_kernel<PREC, WAVES_M, WAVES_N, WM, WN, 1, true>), dim3(grid), dim3(NT), SMEM, stream, k);
     } else if (taps == 1) {
-        static const int cap = resident_grid(conv_gemm_kernel<PREC, WAVES_M, WAVES_N, WM, WN, 1>, SMEM);
+        static const int cap = resident_grid(conv_gemm_kernel<PREC, WAVES_M, WAVES_N, WM, WN, 1>, SMEM, NT);
         const int grid = k.nblk < cap ? k.nblk : cap;
-        hipLaunchKernelGGL((conv_gemm_kernel<PREC, WAVES_M, WAVES_N, WM, WN, 1>), dim3(grid), dim3(256), SMEM, stream, k);
+        hipLaunchKernelGGL((conv_gemm_kernel<PREC, WAVES_M, WAVES_N, WM, WN, 1>), dim3(grid), dim3(NT), SMEM, stream, k);
     } else {
-        static const int cap = resident_grid(conv_gemm_kernel<PREC, WAVES_M, WAVES_N, WM, WN, 9>, SMEM);
+        static const int cap = resident_grid(conv_gemm_kernel<PREC, WAVES_M, WAVES_N, WM, WN, 9>, SMEM, NT);
         const int grid = k.nblk < cap ? k.nblk : cap;
-        hipLaunchKernelGGL((conv_gemm_kernel<PREC, WAVES_M, WAVES_N, WM, WN, 9>), dim3(grid), dim3(256), SMEM, stream, k);
+        hipLaunchKernelGGL((conv_gemm_kernel<PREC, WAVES_M, WAVES_N, WM, WN, 9>), dim3(grid), dim3(NT), SMEM, stream, k);
     }
     return uavsal_launch_status();
 }
@@ -787,6 +831,7 @@ int launch_f32_dma(const ConvK& k0, int taps, hipStream_t stream) {
 
 int launch_f32(const ConvK& k, int taps, int tile, hipStream_t stream) {
     switch (tile) {
+        case 5:
         case 1: return launch_f32_dma<2, 2, 2, 2, 3, 1>(k, taps, stream);    // 128 x 128, 3 x 16 KB ring
         case 2: return launch_f32_dma<4, 1, 1, 2, 4, 1>(k, taps, stream);    // 128 x 64,  4 x 12 KB
         case 3: return launch_f32_dma<4, 1, 1, 1, 4, 1>(k, taps, stream);    // 128 x 32,  4 x 10 KB
@@ -797,7 +842,12 @@ int launch_f32(const ConvK& k, int taps, int tile, hipStream_t stream) {
 
 template <int PREC>
 int launch_prec(const ConvK& k, int taps, int tile, hipStream_t stream) {
+    if constexpr (PREC == UAVSAL_PREC_BF16X3 || PREC == UAVSAL_PREC_F16X3) {
+        // 128 x 256 on 8 waves: one fp32 -> hi/lo conversion of the A tile feeds twice the MFMAs
+        if (tile == 5) return launch_variant<PREC, 2, 4, 2, 2>(k, taps, stream);
+    }
     switch (tile) {
+        case 5:
         case 1: return launch_variant<PREC, 2, 2, 2, 2>(k, taps, stream);   // 128 x 128
         case 2: return launch_variant<PREC, 4, 1, 1, 2>(k, taps, stream);   // 128 x 64
         case 3: return launch_variant<PREC, 4, 1, 1, 1>(k, taps, stream);   // 128 x 32
@@ -805,13 +855,16 @@ int launch_prec(const ConvK& k, int taps, int tile, hipStream_t stream) {
     }
 }
 
-int pick_tile(long long M, int Cout) {
+int pick_tile(long long M, int Cout, int prec) {
     // Largest tile that still hands every one of the 256 CUs at least one workgroup: measured on
     // the path's shapes (profiles/r1_gemm_probe.log) 128x128 beats 128x64 / 64x64 as soon as there
     // are >= 256 tiles (K=1536,N=256: 92 vs 73 TFLOP/s; 3x3 448->256: 91 vs 67), because the
     // per-tile L2 traffic per FLOP halves.  N tile never wider than the 32-padded channel count.
     const int npad = (Cout + 31) / 32 * 32;
     if (npad <= 32) return 3;
+    if ((prec == UAVSAL_PREC_F16X3 || prec == UAVSAL_PREC_BF16X3) && Cout % 256 == 0 &&
+        ((M + 127) / 128) * (Cout / 256) >= 192)
+        return 5;     // split 16-bit: the conversion VALU work and the L2 traffic per FLOP bound these
     const int cand_bm[4] = {128, 128, 128, 64};
     const int cand_bn[4] = {128, 64, 32, 64};
     for (int t = 0; t < 4; ++t) {
@@ -827,8 +880,8 @@ int pick_tile(long long M, int Cout) {
 extern "C" int uavsal_conv_tile(const uavsal_conv_desc* d) {
     if (!d || d->n_img <= 0 || d->H <= 0 || d->W <= 0 || d->Cout <= 0) return UAVSAL_EINVAL;
     if (d->epi == UAVSAL_EPI_LSTM) return 4;
-    if (d->tile >= 1 && d->tile <= 4) return d->tile;
-    return pick_tile((long long)d->H * d->W * d->n_img, d->Cout);
+    if (d->tile >= 1 && d->tile <= 5) return d->tile;
+    return pick_tile((long long)d->H * d->W * d->n_img, d->Cout, d->prec);
 }
 
 extern "C" int uavsal_conv_gemm(const uavsal_conv_desc* d, uavsal_stream_t stream) {
@@ -882,7 +935,7 @@ extern "C" int uavsal_conv_gemm(const uavsal_conv_desc* d, uavsal_stream_t strea
     k.act = d->act; k.epi = d->epi;
     k.contig = ((k.a_is == HW || k.dw_w) && k.o_is == HW && k.r_is == HW && k.x_is == HW) ? 1 : 0;
     k.tiles_n = 0; k.nblk = 0;
-    int tile = (d->tile >= 1 && d->tile <= 4) ? d->tile : pick_tile(M, d->Cout);
+    int tile = (d->tile >= 1 && d->tile <= 5) ? d->tile : pick_tile(M, d->Cout, d->prec);
     if (d->epi == UAVSAL_EPI_LSTM) tile = 4;     // the LSTM update lives in the 64x64 tile's vector epilogue
     hipStream_t s = (hipStream_t)stream;
     switch (d->prec) {
