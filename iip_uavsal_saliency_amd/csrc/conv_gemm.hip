@@ -56,8 +56,9 @@ __device__ __forceinline__ long long row_off(int m, int HW, long long img_stride
     return (long long)img * img_stride + (m - img * HW);
 }
 
-// F16X3 pre-scales: activations by 2^4 while staging (saturating at the fp16 range, i.e.
-// |x| > 4094 clips), weights by 2^6 on the host; the accumulator is scaled back by 2^-10.
+// F16X3 pre-scales: activations by 2^4 while staging (saturating at the fp16 range: hi and lo
+// each stop at 65504, i.e. |x| beyond ~8188 clips), weights by 2^6 on the host; the accumulator
+// is scaled back by 2^-10.
 // Powers of two, so nothing is rounded by the scaling itself; it only keeps the low halves
 // of the split away from the fp16 subnormal range.
 #define F16X3_A_SCALE 16.0f
@@ -261,9 +262,12 @@ void conv_gemm_kernel(const ConvK p) {
 
     // ---- per-thread staging coordinates ------------------------------------------------
     const int ch = tid & 3;              // 16-byte chunk within the 64-byte panel row
+    constexpr int ESZ = (PREC == UAVSAL_PREC_F32) ? 4 : 2;
+    const int b_row0 = tid >> 2;
     long long a_base[A_IT];
     int a_y[A_IT], a_x[A_IT];
     bool a_ok[A_IT];
+    unsigned b_off[B_IT];
     auto setup_tile = [&](int t) {
         const int tile_m = t / p.tiles_n;
         const int tile_n = t - tile_m * p.tiles_n;
@@ -286,8 +290,14 @@ void conv_gemm_kernel(const ConvK p) {
                 a_base[it] = (long long)img * p.a_is;   // in pixels; tap offset added per tile
             }
         }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            // rows past the padded weight matrix are clamped, not zeroed: they only feed output
+            // columns >= Cout, which the epilogue never stores (and a clamp keeps the load branch-free)
+            const int nn = min(n0 + b_row0 + it * (NT / 4), p.Npad - 1);
+            b_off[it] = (unsigned)nn * (unsigned)(p.Kpad * ESZ) + ch * 16;   // host checks < 2^31
+        }
     };
-    const int b_row0 = tid >> 2;
     // opaque to the optimiser: with a known global on one arm it turns `*(ok ? p : zero)` back into
     // a divergent branch around two loads
     size_t zero_page = (size_t)g_zero16;
@@ -370,15 +380,11 @@ void conv_gemm_kernel(const ConvK p) {
         }
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
-            const int row = b_row0 + it * (NT / 4);
-            // rows past the padded weight matrix are clamped, not zeroed: they only feed output
-            // columns >= Cout, which the epilogue never stores (and a clamp keeps the load branch-free)
-            const int nn = min(n0 + row, p.Npad - 1);
 #pragma unroll
             for (int pn = 0; pn < NPAN; ++pn) {
-                const size_t esz = (PREC == UAVSAL_PREC_F32) ? 4 : 2;
-                const size_t elem = ((size_t)pn * p.Npad + nn) * p.Kpad + (size_t)kt * KT;
-                b_reg[set][it][pn] = *reinterpret_cast<const u32x4*>(p.w + elem * esz + ch * 16);
+                // wave-uniform base (panel, K step) + the lane's 32-bit row offset from setup_tile
+                const char* base = p.w + ((size_t)pn * p.Npad * p.Kpad + (size_t)kt * KT) * ESZ;
+                b_reg[set][it][pn] = *reinterpret_cast<const u32x4*>(base + b_off[it]);
             }
         }
     };
@@ -392,6 +398,28 @@ void conv_gemm_kernel(const ConvK p) {
             const int slot = (row * 4 + (ch ^ ((row >> 2) & 3))) * 16;
             if (PREC == UAVSAL_PREC_F32) {
                 *reinterpret_cast<f32x4*>(As + slot) = a_reg[set][it][0];
+            } else if (PREC == UAVSAL_PREC_F16X3) {
+                // The conversion VALU work bounds this kernel, so the split is kept to ~3.5 instructions
+                // per element: packed scale, v_cvt_pkrtz (two elements per instruction; round-toward-zero
+                // overflows to the largest finite half, so no clamp is needed and nothing becomes inf),
+                // unpack, packed subtract, v_cvt_pkrtz.  lo = x - hi is exact in fp32 whatever the
+                // rounding of hi, so RTZ costs one bit of the ~21 (2^-20 relative), not correctness.
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                typedef __fp16 h2 __attribute__((ext_vector_type(2)));
+                u32x4 hi, lo;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 src = a_reg[set][it][(q >> 1) * (NLD - 1)];
+                    f2 x = (q & 1) ? (f2){src.z, src.w} : (f2){src.x, src.y};
+                    x = x * F16X3_A_SCALE;
+                    const h2 h = __builtin_amdgcn_cvt_pkrtz(x.x, x.y);
+                    const f2 r = x - (f2){(float)h.x, (float)h.y};
+                    const h2 l = __builtin_amdgcn_cvt_pkrtz(r.x, r.y);
+                    hi[q] = __builtin_bit_cast(unsigned, h);
+                    lo[q] = __builtin_bit_cast(unsigned, l);
+                }
+                *reinterpret_cast<u32x4*>(As + slot) = hi;
+                *reinterpret_cast<u32x4*>(As + APAN + slot) = lo;
             } else {
                 const f32x4 x0 = prescale<PREC>(a_reg[set][it][0]), x1 = prescale<PREC>(a_reg[set][it][NLD - 1]);
                 u32x4 hi;
@@ -932,6 +960,7 @@ extern "C" int uavsal_conv_gemm(const uavsal_conv_desc* d, uavsal_stream_t strea
     k.Kpad = (d->taps * d->Cin + KT - 1) / KT * KT;
     k.Npad = (d->Cout + 31) / 32 * 32;
     k.ktiles = k.Kpad / KT;
+    if ((long long)k.Npad * k.Kpad * 4 > 0x7fffffffLL) return UAVSAL_ESHAPE;   // 32-bit weight row offsets
     k.act = d->act; k.epi = d->epi;
     k.contig = ((k.a_is == HW || k.dw_w) && k.o_is == HW && k.r_is == HW && k.x_is == HW) ? 1 : 0;
     k.tiles_n = 0; k.nblk = 0;

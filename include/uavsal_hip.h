@@ -48,7 +48,7 @@ extern "C" {
 #define UAVSAL_PREC_BF16X3  1 /* 3x v_mfma_f32_32x32x16_bf16 on a hi/lo bf16 split, fp32 accumulate */
 #define UAVSAL_PREC_BF16    2 /* 1x bf16 MFMA, fp32 accumulate */
 #define UAVSAL_PREC_F16X3   3 /* 3x v_mfma_f32_32x32x16_f16 on a hi/lo fp16 split (22 mantissa bits), fp32 accumulate;
-                                 activations are pre-scaled by 2^4 (|x| > 4094 saturates), weights by 2^6 */
+                                 activations are pre-scaled by 2^4 (finite for any finite x: saturates near |x| = 8188), weights by 2^6 */
 
 #define UAVSAL_ACT_NONE     0
 #define UAVSAL_ACT_RELU6    1 /* nn.ReLU6, model.py:71 */
