@@ -230,19 +230,20 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64,
                              (WM * WN >= 4) ? ((PREC == UAVSAL_PREC_BF16X3 || PREC == UAVSAL_PREC_F16X3 || WAVES_M * WAVES_N == 8) ? 2 : 3) : 4)
 void conv_gemm_kernel(const ConvK p) {
     constexpr int NT = WAVES_M * WAVES_N * 64;     // 4 waves, or 8 for the 128 x 256 tile
+    constexpr int NS = NT;                         // all of them stage operands
     static_assert(!FUSE || TAPS == 1, "the fused depthwise producer feeds a 1x1 projection");
     constexpr int BM = WAVES_M * WM * 32;
     constexpr int BN = WAVES_N * WN * 32;
     constexpr int KT = (PREC == UAVSAL_PREC_F32) ? 16 : 32;
     constexpr int NPAN = (PREC == UAVSAL_PREC_BF16X3 || PREC == UAVSAL_PREC_F16X3) ? 2 : 1;
     constexpr int NLD = (PREC == UAVSAL_PREC_F32) ? 1 : 2;   // float4 loads per A chunk
-    constexpr int A_IT = (BM * 4) / NT;
-    constexpr int B_IT = (BN * 4 + NT - 1) / NT;
+    constexpr int A_IT = (BM * 4) / NS;
+    constexpr int B_IT = (BN * 4 + NS - 1) / NS;
     constexpr int APAN = BM * 64;
     constexpr int BPAN = BN * 64;
     constexpr int STAGE = NPAN * (APAN + BPAN);
-    static_assert(NT == 256 || NT == 512, "4 or 8 waves per workgroup");
-    static_assert((BM * 4) % NT == 0, "A tile must divide over the workgroup's threads");
+    static_assert(NS == 256 || NS == 512, "4 or 8 staging waves per workgroup");
+    static_assert((BM * 4) % NS == 0, "A tile must divide over the staging threads");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -261,9 +262,10 @@ void conv_gemm_kernel(const ConvK p) {
     int m0 = 0, n0 = 0;
 
     // ---- per-thread staging coordinates ------------------------------------------------
-    const int ch = tid & 3;              // 16-byte chunk within the 64-byte panel row
+    const int stid = tid;
+    const int ch = stid & 3;             // 16-byte chunk within the 64-byte panel row
     constexpr int ESZ = (PREC == UAVSAL_PREC_F32) ? 4 : 2;
-    const int b_row0 = tid >> 2;
+    const int b_row0 = stid >> 2;
     long long a_base[A_IT];
     int a_y[A_IT], a_x[A_IT];
     bool a_ok[A_IT];
@@ -275,7 +277,7 @@ void conv_gemm_kernel(const ConvK p) {
         n0 = tile_n * BN;
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
-            const int row = (tid >> 2) + it * (NT / 4);
+            const int row = (stid >> 2) + it * (NS / 4);
             const int m = m0 + row;
             a_ok[it] = m < p.M;
             const int mm = a_ok[it] ? m : 0;
@@ -294,8 +296,8 @@ void conv_gemm_kernel(const ConvK p) {
         for (int it = 0; it < B_IT; ++it) {
             // rows past the padded weight matrix are clamped, not zeroed: they only feed output
             // columns >= Cout, which the epilogue never stores (and a clamp keeps the load branch-free)
-            const int nn = min(n0 + b_row0 + it * (NT / 4), p.Npad - 1);
-            b_off[it] = (unsigned)nn * (unsigned)(p.Kpad * ESZ) + ch * 16;   // host checks < 2^31
+            const int nn = min(n0 + b_row0 + it * (NS / 4), p.Npad - 1);
+            b_off[it] = (unsigned)nn * 64u + ch * 16;     // K-step-major weights: one 64-byte row per n
         }
     };
     // opaque to the optimiser: with a known global on one arm it turns `*(ok ? p : zero)` back into
@@ -383,7 +385,7 @@ void conv_gemm_kernel(const ConvK p) {
 #pragma unroll
             for (int pn = 0; pn < NPAN; ++pn) {
                 // wave-uniform base (panel, K step) + the lane's 32-bit row offset from setup_tile
-                const char* base = p.w + ((size_t)pn * p.Npad * p.Kpad + (size_t)kt * KT) * ESZ;
+                const char* base = p.w + ((size_t)kt * NPAN + pn) * p.Npad * 64;
                 b_reg[set][it][pn] = *reinterpret_cast<const u32x4*>(base + b_off[it]);
             }
         }
@@ -394,7 +396,7 @@ void conv_gemm_kernel(const ConvK p) {
         char* Bs = As + NPAN * APAN;
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
-            const int row = (tid >> 2) + it * (NT / 4);
+            const int row = (stid >> 2) + it * (NS / 4);
             const int slot = (row * 4 + (ch ^ ((row >> 2) & 3))) * 16;
             if (PREC == UAVSAL_PREC_F32) {
                 *reinterpret_cast<f32x4*>(As + slot) = a_reg[set][it][0];
@@ -438,8 +440,8 @@ void conv_gemm_kernel(const ConvK p) {
         }
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
-            const int row = b_row0 + it * (NT / 4);
-            if ((BN * 4) % NT == 0 || row < BN) {
+            const int row = b_row0 + it * (NS / 4);
+            if ((BN * 4) % NS == 0 || row < BN) {
                 const int slot = (row * 4 + (ch ^ ((row >> 2) & 3))) * 16;
 #pragma unroll
                 for (int pn = 0; pn < NPAN; ++pn)
@@ -708,7 +710,7 @@ __global__ __launch_bounds__(256, (WM * WN >= 4) ? 3 : 4) void conv_gemm_f32_dma
                 const int nn = n0 + row;
                 const float* src = zero;
                 if (kin && row < BN && nn < p.Npad)
-                    src = reinterpret_cast<const float*>(p.w) + (size_t)nn * p.Kpad + (size_t)kt * KT + b_lc[it] * 4;
+                    src = reinterpret_cast<const float*>(p.w) + ((size_t)kt * p.Npad + nn) * KT + b_lc[it] * 4;
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Bs + (it * 64 + wrow) * 64), 16, 0, 0);
             }
         }
@@ -960,7 +962,7 @@ extern "C" int uavsal_conv_gemm(const uavsal_conv_desc* d, uavsal_stream_t strea
     k.Kpad = (d->taps * d->Cin + KT - 1) / KT * KT;
     k.Npad = (d->Cout + 31) / 32 * 32;
     k.ktiles = k.Kpad / KT;
-    if ((long long)k.Npad * k.Kpad * 4 > 0x7fffffffLL) return UAVSAL_ESHAPE;   // 32-bit weight row offsets
+    if ((long long)k.Npad * 64 > 0x7fffffffLL) return UAVSAL_ESHAPE;   // 32-bit weight row offsets
     k.act = d->act; k.epi = d->epi;
     k.contig = ((k.a_is == HW || k.dw_w) && k.o_is == HW && k.r_is == HW && k.x_is == HW) ? 1 : 0;
     k.tiles_n = 0; k.nblk = 0;

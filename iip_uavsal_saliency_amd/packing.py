@@ -48,20 +48,21 @@ def pack_conv_weight(w: torch.Tensor, prec: str) -> torch.Tensor:
     kpad, npad = roundup(k, kt), roundup(cout, 32)
     m = torch.zeros(npad, kpad, dtype=torch.float32)
     m[:cout, :k] = w.permute(0, 2, 3, 1).reshape(cout, k)        # k = tap*Cin + ci
+    # K-step-major: [Kpad/kt][panel][Npad][kt] -- the rows of one K step are one contiguous run
     if prec == "f32":
-        return m.contiguous().view(torch.uint8).reshape(-1)
+        return m.view(npad, kpad // 16, 16).permute(1, 0, 2).contiguous().view(torch.uint8).reshape(-1)
     idx = torch.tensor(_K_PERM32, dtype=torch.long)
-    m = m.view(npad, kpad // 32, 32)[:, :, idx].reshape(npad, kpad)
+    m = m.view(npad, kpad // 32, 32)[:, :, idx]                 # [npad, steps, 32]
     if prec == "f16x3":
         m = m * 64.0
         hi = m.to(torch.float16)
         lo = (m - hi.float()).to(torch.float16)
-        return torch.stack([hi, lo], 0).contiguous().view(torch.uint8).reshape(-1)
+        return torch.stack([hi, lo], 0).permute(2, 0, 1, 3).contiguous().view(torch.uint8).reshape(-1)
     hi = m.to(torch.bfloat16)
     if prec == "bf16":
-        return hi.contiguous().view(torch.uint8).reshape(-1)
+        return hi.permute(1, 0, 2).contiguous().view(torch.uint8).reshape(-1)
     lo = (m - hi.float()).to(torch.bfloat16)
-    return torch.stack([hi, lo], 0).contiguous().view(torch.uint8).reshape(-1)
+    return torch.stack([hi, lo], 0).permute(2, 0, 1, 3).contiguous().view(torch.uint8).reshape(-1)
 
 
 def pack_dw_weight(w: torch.Tensor) -> torch.Tensor:

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define UAVSAL_ABI_VERSION 4
+#define UAVSAL_ABI_VERSION 5
 
 /* argument errors */
 #define UAVSAL_EINVAL   (-1)  /* null pointer / non-positive size */
@@ -88,9 +88,12 @@ typedef void* uavsal_stream_t;
  * Weights `w` are pre-packed by the host (iip_uavsal_saliency_amd/packing.py):
  *   k index = tap * Cin + ci, rows padded to Npad = roundup(Cout, 32), K padded to
  *   Kpad = roundup(taps * Cin, KT) with zeros, KT = 16 (F32) or 32 (BF16*, F16X3);
- *   F32:    float  [Npad][Kpad]
- *   BF16:   uint16 [Npad][Kpad]            (bf16 bits, round-to-nearest-even)
- *   BF16X3: uint16 hi[Npad][Kpad] then uint16 lo[Npad][Kpad], lo = bf16(w - hi)
+ *   K-step-major, so that the weight rows one K step needs are ONE contiguous run of whole
+ *   cache lines (with [Npad][Kpad] every step touched half of a 128-byte line per row and the
+ *   line was fetched from L2 again for the next step):
+ *   F32:    float  [Kpad/16][Npad][16]
+ *   BF16:   uint16 [Kpad/32][Npad][32]     (bf16 bits, round-to-nearest-even)
+ *   BF16X3: uint16 [Kpad/32][2][Npad][32]  ([.][0] = hi, [.][1] = lo = bf16(w - hi))
  *   F16X3:  as BF16X3 with fp16 bits of ws = 64*w: hi = fp16(ws), lo = fp16(ws - hi)
  *   in the BF16* / F16X3 layouts each group of 32 k's is stored in the order
  *   {0-3,16-19, 4-7,20-23, 8-11,24-27, 12-15,28-31} (matches the A staging).

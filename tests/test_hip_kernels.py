@@ -91,12 +91,13 @@ def test_conv1x1_all_tiles(ops, prec, tile):
     assert err <= TOL[prec] * 4.0, (tile, prec, err)
 
 
+@pytest.mark.parametrize("tile", [1, 5])
 @pytest.mark.parametrize("prec", ["f16x3", "bf16x3"])
 @pytest.mark.parametrize("case", [(3, 20, 23, 96, 512, 1, True), (2, 20, 23, 1536, 256, 1, False),
-                                  (2, 12, 15, 64, 256, 9, False)])
-def test_conv_wide_tile(ops, prec, case):
-    """The 8-wave 128 x 256 tile of the split 16-bit precisions (expand / project / 3x3 shapes),
-    BN + ReLU6 + residual epilogue."""
+                                  (2, 12, 15, 64, 256, 9, False), (2, 20, 23, 72, 200, 1, True)])
+def test_conv_wide_tile(ops, prec, case, tile):
+    """The big tiles of the split 16-bit precisions (128 x 128, and 128 x 256 on 8 waves) on expand /
+    project / 3x3 / ragged shapes, odd K-step counts, BN + ReLU6 + residual epilogue."""
     n, h, w, cin, cout, taps, use_res = case
     x = rnd((n, cin, h, w), 71, 2.0)
     k = 3 if taps == 9 else 1
@@ -107,7 +108,7 @@ def test_conv_wide_tile(ops, prec, case):
     res = rnd((n, cout, h, w), 75, 1.0)
     if use_res:
         ref = ref + res
-    got = ops.conv_gemm(nhwc(x), wt, scale, bias, act=1, res=nhwc(res) if use_res else None, prec=prec, tile=5)
+    got = ops.conv_gemm(nhwc(x), wt, scale, bias, act=1, res=nhwc(res) if use_res else None, prec=prec, tile=tile)
     err = (nchw(got) - ref).abs().max().item()
     assert err <= TOL[prec] * 4.0, (case, prec, err)
 

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert declared == bound, (declared ^ bound)
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.uavsal_abi_version() == 4
+    assert lib.uavsal_abi_version() == 5
     assert b"gfx950" in lib.uavsal_build_info()
 
 
@@ -80,17 +80,17 @@ def test_pack_conv_weight_layouts(shape):
     ref = w.permute(0, 2, 3, 1).reshape(cout, k)                 # k = tap*Cin + ci
     f = P.pack_conv_weight(w, "f32").view(torch.float32)
     npad, kpad = P.roundup(cout, 32), P.roundup(k, 16)
-    f = f.view(npad, kpad)
+    f = f.view(kpad // 16, npad, 16).permute(1, 0, 2).reshape(npad, kpad)      # K-step-major -> [n][k]
     assert torch.equal(f[:cout, :k], ref) and f[cout:].abs().sum() == 0 and f[:, k:].abs().sum() == 0
     kpad = P.roundup(k, 32)
     inv = torch.empty(32, dtype=torch.long)
     inv[torch.tensor(P._K_PERM32)] = torch.arange(32)
     for prec, dt, scale, tol in (("bf16x3", torch.bfloat16, 1.0, 2.0 ** -15), ("f16x3", torch.float16, 64.0, 2.0 ** -20)):
-        hl = P.pack_conv_weight(w, prec).view(dt).view(2, npad, kpad).float()
-        rec = (hl[0] + hl[1]).view(npad, kpad // 32, 32)[:, :, inv].reshape(npad, kpad) / scale
+        hl = P.pack_conv_weight(w, prec).view(dt).view(kpad // 32, 2, npad, 32).float()   # [step][hi|lo][n][32]
+        rec = (hl[:, 0] + hl[:, 1]).permute(1, 0, 2)[:, :, inv].reshape(npad, kpad) / scale
         assert (rec[:cout, :k] - ref).abs().max().item() <= tol * ref.abs().max().item()
-    h1 = P.pack_conv_weight(w, "bf16").view(torch.bfloat16).view(npad, kpad)
-    assert torch.equal(h1, P.pack_conv_weight(w, "bf16x3").view(torch.bfloat16).view(2, npad, kpad)[0])
+    h1 = P.pack_conv_weight(w, "bf16").view(torch.bfloat16).view(kpad // 32, npad, 32)
+    assert torch.equal(h1, P.pack_conv_weight(w, "bf16x3").view(torch.bfloat16).view(kpad // 32, 2, npad, 32)[:, 0])
 
 
 def test_pack_dw_and_stem():
