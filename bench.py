@@ -17,7 +17,7 @@ Extra objects on that line:
   cpu_baseline  the oracle (CPU restatement, torch fp32) timed on this box's
                 host cores on ONE clip of the same workload (bounded sample).
   parity        max-abs of the saliency map vs that CPU run on the same inputs.
-  extra         BASELINE.json configs[2]-shaped run (8 clips, split-fp16 MFMA, hipGraph).
+  extra         the same workload and BASELINE.json's configs[2] shape (8 clips) in split-fp16 MFMA.
 """
 import argparse
 import json
@@ -266,19 +266,26 @@ def main():
             serr = (last["state"][:1].cpu() - ref_state).abs().max().item()
             result["parity"] = {"max_abs_map_vs_cpu_ref": float("%.3e" % err), "max_abs_state_vs_cpu_ref": float("%.3e" % serr),
                                 "tolerance": 1e-3}
-        if not args.no_extra and (C, args.prec) != (8, "f16x3"):
-            log("extra: 8 clips, f16x3, hipGraph")
+        if not args.no_extra and args.prec == "f32":
+            # the same workload, and BASELINE.json's configs[2] shape, in the split-fp16 precision
+            # (fp32-class: held to the 5e-4 parity bound by tests/test_hip_e2e.py); informative only
+            log("extra: f16x3 at 1 and 8 clips")
             try:
                 m2 = UAVSal(time_dims=T, precision="f16x3")
                 synth.load_synth_weights(m2, 0)
                 m2 = m2.to(device).eval()
-                m2.use_graph = True
-                x8, cb8 = make_clips(8, T, H, W)
-                x8 = x8.to(device)
-                cb8 = [cb8[0].to(device), cb8[1].to(device)]
-                dt8 = timed_steps(lambda: m2.forward_clips(x8, cb8, None), max(5, args.steps // 2), 2, False, device)
-                result["extra"] = {"workload": "%dx%d batch=8 seq=%d, prec=f16x3 (3x f16 split MFMA), hipGraph" % (H, W, T),
-                                   "value": round(8 * T * max(5, args.steps // 2) / dt8, 2), "unit": "frames/s"}
+                extra = {"precision": "f16x3 (3x f16 split MFMA, f32 accumulate)", "unit": "frames/s"}
+                ksteps = max(5, args.steps // 2)
+                for c2 in (1, 8):
+                    x8, cb8 = make_clips(c2, T, H, W)
+                    x8 = x8.to(device)
+                    cb8 = [cb8[0].to(device), cb8[1].to(device)]
+                    dt8 = timed_steps(lambda: m2.forward_clips(x8, cb8, None), ksteps, 2, False, device)
+                    extra["%dx%d batch=%d seq=%d" % (H, W, c2, T)] = round(c2 * T * ksteps / dt8, 2)
+                    if c2 == 1 and "cpu_baseline" in result:
+                        o1, _ = m2.forward_clips(x8, cb8, None)
+                        extra["max_abs_map_vs_cpu_ref"] = float("%.3e" % (o1.cpu() - ref_out).abs().max().item())
+                result["extra"] = extra
             except Exception as e:  # extra is informative only
                 result["extra"] = {"error": repr(e)[:200]}
 

@@ -297,7 +297,8 @@ void conv_gemm_kernel(const ConvK p) {
             // rows past the padded weight matrix are clamped, not zeroed: they only feed output
             // columns >= Cout, which the epilogue never stores (and a clamp keeps the load branch-free)
             const int nn = min(n0 + b_row0 + it * (NS / 4), p.Npad - 1);
-            b_off[it] = (unsigned)nn * 64u + ch * 16;     // K-step-major weights: one 64-byte row per n
+            // 16-bit layouts are K-step-major (one 64-byte row per n and step); fp32 is [Npad][Kpad]
+            b_off[it] = (unsigned)nn * (PREC == UAVSAL_PREC_F32 ? (unsigned)p.Kpad * 4u : 64u) + ch * 16;
         }
     };
     // opaque to the optimiser: with a known global on one arm it turns `*(ok ? p : zero)` back into
@@ -385,7 +386,8 @@ void conv_gemm_kernel(const ConvK p) {
 #pragma unroll
             for (int pn = 0; pn < NPAN; ++pn) {
                 // wave-uniform base (panel, K step) + the lane's 32-bit row offset from setup_tile
-                const char* base = p.w + ((size_t)kt * NPAN + pn) * p.Npad * 64;
+                const char* base = (PREC == UAVSAL_PREC_F32) ? p.w + (size_t)kt * 64
+                                                             : p.w + ((size_t)kt * NPAN + pn) * p.Npad * 64;
                 b_reg[set][it][pn] = *reinterpret_cast<const u32x4*>(base + b_off[it]);
             }
         }
@@ -710,7 +712,7 @@ __global__ __launch_bounds__(256, (WM * WN >= 4) ? 3 : 4) void conv_gemm_f32_dma
                 const int nn = n0 + row;
                 const float* src = zero;
                 if (kin && row < BN && nn < p.Npad)
-                    src = reinterpret_cast<const float*>(p.w) + ((size_t)kt * p.Npad + nn) * KT + b_lc[it] * 4;
+                    src = reinterpret_cast<const float*>(p.w) + (size_t)nn * p.Kpad + (size_t)kt * KT + b_lc[it] * 4;
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Bs + (it * 64 + wrow) * 64), 16, 0, 0);
             }
         }
@@ -962,7 +964,7 @@ extern "C" int uavsal_conv_gemm(const uavsal_conv_desc* d, uavsal_stream_t strea
     k.Kpad = (d->taps * d->Cin + KT - 1) / KT * KT;
     k.Npad = (d->Cout + 31) / 32 * 32;
     k.ktiles = k.Kpad / KT;
-    if ((long long)k.Npad * 64 > 0x7fffffffLL) return UAVSAL_ESHAPE;   // 32-bit weight row offsets
+    if ((long long)k.Npad * k.Kpad * 4 > 0x7fffffffLL) return UAVSAL_ESHAPE;   // 32-bit weight row offsets
     k.act = d->act; k.epi = d->epi;
     k.contig = ((k.a_is == HW || k.dw_w) && k.o_is == HW && k.r_is == HW && k.x_is == HW) ? 1 : 0;
     k.tiles_n = 0; k.nblk = 0;

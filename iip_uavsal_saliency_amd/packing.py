@@ -48,9 +48,9 @@ def pack_conv_weight(w: torch.Tensor, prec: str) -> torch.Tensor:
     kpad, npad = roundup(k, kt), roundup(cout, 32)
     m = torch.zeros(npad, kpad, dtype=torch.float32)
     m[:cout, :k] = w.permute(0, 2, 3, 1).reshape(cout, k)        # k = tap*Cin + ci
-    # K-step-major: [Kpad/kt][panel][Npad][kt] -- the rows of one K step are one contiguous run
     if prec == "f32":
-        return m.view(npad, kpad // 16, 16).permute(1, 0, 2).contiguous().view(torch.uint8).reshape(-1)
+        return m.contiguous().view(torch.uint8).reshape(-1)
+    # 16-bit layouts are K-step-major: [Kpad/32][panel][Npad][32] -- one K step is one contiguous run
     idx = torch.tensor(_K_PERM32, dtype=torch.long)
     m = m.view(npad, kpad // 32, 32)[:, :, idx]                 # [npad, steps, 32]
     if prec == "f16x3":

@@ -88,10 +88,10 @@ typedef void* uavsal_stream_t;
  * Weights `w` are pre-packed by the host (iip_uavsal_saliency_amd/packing.py):
  *   k index = tap * Cin + ci, rows padded to Npad = roundup(Cout, 32), K padded to
  *   Kpad = roundup(taps * Cin, KT) with zeros, KT = 16 (F32) or 32 (BF16*, F16X3);
- *   K-step-major, so that the weight rows one K step needs are ONE contiguous run of whole
- *   cache lines (with [Npad][Kpad] every step touched half of a 128-byte line per row and the
- *   line was fetched from L2 again for the next step):
- *   F32:    float  [Kpad/16][Npad][16]
+ *   F32:    float  [Npad][Kpad]
+ *   The 16-bit layouts are K-step-major, so that the weight rows one K step needs are ONE
+ *   contiguous run of whole cache lines (measured +4..7 % on the split GEMMs; the LDS-DMA
+ *   fp32 kernel measured 2..6 % slower with it and keeps the row-major layout):
  *   BF16:   uint16 [Kpad/32][Npad][32]     (bf16 bits, round-to-nearest-even)
  *   BF16X3: uint16 [Kpad/32][2][Npad][32]  ([.][0] = hi, [.][1] = lo = bf16(w - hi))
  *   F16X3:  as BF16X3 with fp16 bits of ws = 64*w: hi = fp16(ws), lo = fp16(ws - hi)

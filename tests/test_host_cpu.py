@@ -80,7 +80,7 @@ def test_pack_conv_weight_layouts(shape):
     ref = w.permute(0, 2, 3, 1).reshape(cout, k)                 # k = tap*Cin + ci
     f = P.pack_conv_weight(w, "f32").view(torch.float32)
     npad, kpad = P.roundup(cout, 32), P.roundup(k, 16)
-    f = f.view(kpad // 16, npad, 16).permute(1, 0, 2).reshape(npad, kpad)      # K-step-major -> [n][k]
+    f = f.view(npad, kpad)
     assert torch.equal(f[:cout, :k], ref) and f[cout:].abs().sum() == 0 and f[:, k:].abs().sum() == 0
     kpad = P.roundup(k, 32)
     inv = torch.empty(32, dtype=torch.long)
