@@ -41,7 +41,7 @@ PREC_ID = {"f32": 0, "bf16x3": 1, "bf16": 2, "f16x3": 3}
 # template arguments of the kernel instance each (precision, tile) launches, as rocprofv3 prints them
 F32_INST = {1: "2, 2, 2, 2, %d, 3, 1", 2: "4, 1, 1, 2, %d, 4, 1", 3: "4, 1, 1, 1, %d, 4, 1", 4: "2, 2, 1, 1, %d, 3, 4"}
 H16_INST = {1: "%d, 2, 2, 2, 2, %d", 2: "%d, 4, 1, 1, 2, %d", 3: "%d, 4, 1, 1, 1, %d", 4: "%d, 2, 2, 1, 1, %d",
-            5: "%d, 2, 4, 2, 2, %d"}
+            5: "%d, 2, 4, 2, 2, %d", 6: "%d, 2, 4, 4, 2, %d"}
 
 
 def kernel_symbol(prec, tile, taps):

@@ -130,15 +130,17 @@ __device__ __forceinline__ f32x4 prescale(f32x4 x) {
             const float lo = p.act == UAVSAL_ACT_RELU6 ? 0.f : -3.0e38f;                             \
             const float hi = p.act == UAVSAL_ACT_RELU6 ? 6.f : 3.0e38f;                              \
             float* stg = reinterpret_cast<float*>(STG);                                              \
-            _Pragma("unroll") for (int pp = 0; pp < BM / 32; ++pp) {                                 \
-                _Pragma("unroll") for (int i = 0; i < WM; ++i) {                                     \
-                    if (wm * WM + i == pp) {                                                         \
-                        _Pragma("unroll") for (int g = 0; g < 16; ++g) {                             \
-                            const int r = (g & 3) + 8 * (g >> 2) + 4 * lh;                           \
-                            _Pragma("unroll") for (int j = 0; j < WN; ++j)                           \
-                                stg[r * BN + col[j]] = (twa_ || lstm_) ? acc[i][j][g] * (ACC_SCALE) : \
-                                    __builtin_amdgcn_fmed3f(fmaf(acc[i][j][g], sc[j], bi[j]), lo, hi); \
-                        }                                                                            \
+            /* 32-row block pp = w * WM + i belongs to the waves with wm == w: `i` stays a compile-time \
+               index into the accumulators (a run-time one would demote them to scratch) */           \
+            _Pragma("unroll") for (int i = 0; i < WM; ++i)                                           \
+            _Pragma("unroll") for (int w = 0; w < BM / 32 / WM; ++w) {                               \
+                const int pp = w * WM + i;                                                           \
+                if (wm == w) {                                                                       \
+                    _Pragma("unroll") for (int g = 0; g < 16; ++g) {                                 \
+                        const int r = (g & 3) + 8 * (g >> 2) + 4 * lh;                               \
+                        _Pragma("unroll") for (int j = 0; j < WN; ++j)                               \
+                            stg[r * BN + col[j]] = (twa_ || lstm_) ? acc[i][j][g] * (ACC_SCALE) :    \
+                                __builtin_amdgcn_fmed3f(fmaf(acc[i][j][g], sc[j], bi[j]), lo, hi);   \
                     }                                                                                \
                 }                                                                                    \
                 __syncthreads();                                                                     \
@@ -182,7 +184,7 @@ __device__ __forceinline__ f32x4 prescale(f32x4 x) {
                 }                                                                                    \
                 __syncthreads();                                                                     \
             }                                                                                        \
-        } else {                                                                                     \
+        } else if (WM * WN <= 4) {   /* scalar path; not built for the 256 x 256 tile (host checks) */ \
             _Pragma("unroll") for (int i = 0; i < WM; ++i) {                                         \
                 _Pragma("unroll") for (int g = 0; g < 16; ++g) {                                     \
                     const int m = m0c + (wm * WM + i) * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;        \
@@ -311,7 +313,7 @@ void conv_gemm_kernel(const ConvK p) {
     // the conversion VALU work and the barrier-phased MFMA / VALU alternation, not by load latency:
     // D = 1, 2, 3 are within 3% on the 4-wave tiles (1 is best and cheapest in registers); only the
     // 8-wave 128 x 256 tile, alone on its CU, gains from D = 2 (up to 9% on the 64-frame expands).
-    constexpr int D = (!FUSE && WAVES_M * WAVES_N == 8) ? UAVSAL_GEMM_PREFETCH : 1;
+    constexpr int D = (!FUSE && WAVES_M * WAVES_N == 8 && WM * WN <= 4) ? UAVSAL_GEMM_PREFETCH : 1;
     f32x4 a_reg[D][A_IT][NLD];
     u32x4 b_reg[D][B_IT][NPAN];
 
@@ -826,9 +828,13 @@ int launch_variant(const ConvK& k0, int taps, hipStream_t stream) {
     k.tiles_n = (k.Cout + BN - 1) / BN;
     k.nblk = tiles_m * k.tiles_n;
     if (taps == 1 && k.dw_w) {
-        static const int cap = resident_grid(conv_gemm_kernel<PREC, WAVES_M, WAVES_N, WM, WN, 1, true>, SMEM, NT);
-        const int grid = k.nblk < cap ? k.nblk : cap;
-        hipLaunchKernelGGL((conv_gemm_kernel<PREC, WAVES_M, WAVES_N, WM, WN, 1, true>), dim3(grid), dim3(NT), SMEM, stream, k);
+        if constexpr (WM * WN <= 4) {      // the fused producer is not built for the 256 x 256 tile
+            static const int cap = resident_grid(conv_gemm_kernel<PREC, WAVES_M, WAVES_N, WM, WN, 1, true>, SMEM, NT);
+            const int grid = k.nblk < cap ? k.nblk : cap;
+            hipLaunchKernelGGL((conv_gemm_kernel<PREC, WAVES_M, WAVES_N, WM, WN, 1, true>), dim3(grid), dim3(NT), SMEM, stream, k);
+        } else {
+            return UAVSAL_ESHAPE;
+        }
     } else if (taps == 1) {
         static const int cap = resident_grid(conv_gemm_kernel<PREC, WAVES_M, WAVES_N, WM, WN, 1>, SMEM, NT);
         const int grid = k.nblk < cap ? k.nblk : cap;
@@ -864,6 +870,7 @@ int launch_f32_dma(const ConvK& k0, int taps, hipStream_t stream) {
 int launch_f32(const ConvK& k, int taps, int tile, hipStream_t stream) {
     switch (tile) {
         case 5:
+        case 6:
         case 1: return launch_f32_dma<2, 2, 2, 2, 3, 1>(k, taps, stream);    // 128 x 128, 3 x 16 KB ring
         case 2: return launch_f32_dma<4, 1, 1, 2, 4, 1>(k, taps, stream);    // 128 x 64,  4 x 12 KB
         case 3: return launch_f32_dma<4, 1, 1, 1, 4, 1>(k, taps, stream);    // 128 x 32,  4 x 10 KB
@@ -877,9 +884,12 @@ int launch_prec(const ConvK& k, int taps, int tile, hipStream_t stream) {
     if constexpr (PREC == UAVSAL_PREC_BF16X3 || PREC == UAVSAL_PREC_F16X3) {
         // 128 x 256 on 8 waves: one fp32 -> hi/lo conversion of the A tile feeds twice the MFMAs
         if (tile == 5) return launch_variant<PREC, 2, 4, 2, 2>(k, taps, stream);
+        // 256 x 256 on 8 waves (128 x 64 per wave): half the L2 -> CU bytes per FLOP of 128 x 256
+        if (tile == 6 && !k.dw_w) return launch_variant<PREC, 2, 4, 4, 2>(k, taps, stream);
     }
     switch (tile) {
         case 5:
+        case 6:
         case 1: return launch_variant<PREC, 2, 2, 2, 2>(k, taps, stream);   // 128 x 128
         case 2: return launch_variant<PREC, 4, 1, 1, 2>(k, taps, stream);   // 128 x 64
         case 3: return launch_variant<PREC, 4, 1, 1, 1>(k, taps, stream);   // 128 x 32
@@ -894,9 +904,12 @@ int pick_tile(long long M, int Cout, int prec) {
     // per-tile L2 traffic per FLOP halves.  N tile never wider than the 32-padded channel count.
     const int npad = (Cout + 31) / 32 * 32;
     if (npad <= 32) return 3;
-    if ((prec == UAVSAL_PREC_F16X3 || prec == UAVSAL_PREC_BF16X3) && Cout % 256 == 0 &&
-        ((M + 127) / 128) * (Cout / 256) >= 192)
-        return 5;     // split 16-bit: the conversion VALU work and the L2 traffic per FLOP bound these
+    if ((prec == UAVSAL_PREC_F16X3 || prec == UAVSAL_PREC_BF16X3) && Cout % 256 == 0) {
+        // split 16-bit: the L2 -> CU traffic per FLOP bounds these, so the widest tile that still
+        // leaves every CU two workgroups' worth of tiles (profiles/r1_gemm_probe_v3.log)
+        if (((M + 255) / 256) * (Cout / 256) >= 512) return 6;
+        if (((M + 127) / 128) * (Cout / 256) >= 192) return 5;
+    }
     const int cand_bm[4] = {128, 128, 128, 64};
     const int cand_bn[4] = {128, 64, 32, 64};
     for (int t = 0; t < 4; ++t) {
@@ -912,7 +925,7 @@ int pick_tile(long long M, int Cout, int prec) {
 extern "C" int uavsal_conv_tile(const uavsal_conv_desc* d) {
     if (!d || d->n_img <= 0 || d->H <= 0 || d->W <= 0 || d->Cout <= 0) return UAVSAL_EINVAL;
     if (d->epi == UAVSAL_EPI_LSTM) return 4;
-    if (d->tile >= 1 && d->tile <= 5) return d->tile;
+    if (d->tile >= 1 && d->tile <= 6) return d->tile;
     return pick_tile((long long)d->H * d->W * d->n_img, d->Cout, d->prec);
 }
 
@@ -968,7 +981,13 @@ extern "C" int uavsal_conv_gemm(const uavsal_conv_desc* d, uavsal_stream_t strea
     k.act = d->act; k.epi = d->epi;
     k.contig = ((k.a_is == HW || k.dw_w) && k.o_is == HW && k.r_is == HW && k.x_is == HW) ? 1 : 0;
     k.tiles_n = 0; k.nblk = 0;
-    int tile = (d->tile >= 1 && d->tile <= 5) ? d->tile : pick_tile(M, d->Cout, d->prec);
+    int tile = (d->tile >= 1 && d->tile <= 6) ? d->tile : pick_tile(M, d->Cout, d->prec);
+    if (tile == 6) {   // the 256 x 256 tile only carries the vector epilogue
+        const bool vec = d->epi == UAVSAL_EPI_AFFINE && d->act != UAVSAL_ACT_SIGMOID && !(d->ldc & 3) &&
+                         !(d->Cout & 3) && uavsal_aligned16(d->out) &&
+                         (!d->res || (!(d->ldr & 3) && uavsal_aligned16(d->res)));
+        if (!vec || d->dw_w9c) tile = 5;
+    }
     if (d->epi == UAVSAL_EPI_LSTM) tile = 4;     // the LSTM update lives in the 64x64 tile's vector epilogue
     hipStream_t s = (hipStream_t)stream;
     switch (d->prec) {

@@ -109,8 +109,8 @@ typedef struct uavsal_conv_desc {
     int32_t n_img, H, W;         /* output == input spatial size */
     int32_t Cin, Cout, taps;     /* taps: 1 or 9 */
     int32_t prec, act, epi;
-    int32_t tile;                /* 0 = auto; else 1: 128x128, 2: 128x64, 3: 128x32, 4: 64x64, 5: 128x256 (split 16-bit
-                                  * precisions; others run it as 1) block tile */
+    int32_t tile;                /* 0 = auto; else 1: 128x128, 2: 128x64, 3: 128x32, 4: 64x64, 5: 128x256, 6: 256x256 (split
+                                  * 16-bit precisions; others run them as 1) block tile */
     float*       out2;   int32_t ld2;                 /* EPI_LSTM only: c_t (image stride = o_img_stride) */
     /* Fused depthwise producer (taps == 1, EPI_AFFINE): when dw_w9c != NULL, `a` is the EXPANDED tensor E
      * [n_img, dw_Hin, dw_Win, Cin] of an inverted-residual block and the GEMM's A operand is computed on the
@@ -123,7 +123,7 @@ typedef struct uavsal_conv_desc {
 } uavsal_conv_desc;
 
 int uavsal_conv_gemm(const uavsal_conv_desc* d, uavsal_stream_t stream);
-/* block tile `uavsal_conv_gemm` will use for this descriptor (1..5, see `tile`); no launch */
+/* block tile `uavsal_conv_gemm` will use for this descriptor (1..6, see `tile`); no launch */
 int uavsal_conv_tile(const uavsal_conv_desc* d);
 
 /*

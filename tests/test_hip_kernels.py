@@ -79,7 +79,7 @@ def test_conv1x1(ops, prec, case):
     assert err <= TOL[prec] * 4.0, (case, prec, err)
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("prec", ["f32", "f16x3", "bf16x3"])
 def test_conv1x1_all_tiles(ops, prec, tile):
     n, h, w, cin, cout = 2, 11, 13, 64, 160      # M = 286: ragged against every tile height
@@ -91,12 +91,12 @@ def test_conv1x1_all_tiles(ops, prec, tile):
     assert err <= TOL[prec] * 4.0, (tile, prec, err)
 
 
-@pytest.mark.parametrize("tile", [1, 5])
+@pytest.mark.parametrize("tile", [1, 5, 6])
 @pytest.mark.parametrize("prec", ["f16x3", "bf16x3"])
 @pytest.mark.parametrize("case", [(3, 20, 23, 96, 512, 1, True), (2, 20, 23, 1536, 256, 1, False),
                                   (2, 12, 15, 64, 256, 9, False), (2, 20, 23, 72, 200, 1, True)])
 def test_conv_wide_tile(ops, prec, case, tile):
-    """The big tiles of the split 16-bit precisions (128 x 128, and 128 x 256 on 8 waves) on expand /
+    """The big tiles of the split 16-bit precisions (128 x 128; 128 x 256 and 256 x 256 on 8 waves) on expand /
     project / 3x3 / ragged shapes, odd K-step counts, BN + ReLU6 + residual epilogue."""
     n, h, w, cin, cout, taps, use_res = case
     x = rnd((n, cin, h, w), 71, 2.0)

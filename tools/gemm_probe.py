@@ -53,8 +53,8 @@ if __name__ == "__main__":
     precs = sys.argv[1].split(",") if len(sys.argv) > 1 else ["f32", "f16x3"]
     for prec in precs:
         for sh in shapes:
-            for tile in (1, 2, 4, 5):
-                if tile == 5 and (prec == "f32" or sh[3] % 256):
+            for tile in (1, 2, 4, 5, 6):
+                if tile in (5, 6) and (prec == "f32" or sh[3] % 256):
                     continue
                 if sh[3] < 64 and tile != 1:
                     continue
