@@ -30,6 +30,34 @@ __device__ __forceinline__ int xcd_virtual_block(int bid, int nblk) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
 }
 
+// Persistent-workgroup tile walk of the GEMMs.  Each XCD owns one contiguous range of output
+// tiles; inside it the XCD's workgroups take tiles round-robin (tile, tile + stride, ...), so at
+// any moment they sit on neighbouring tiles: the activation rows and weight rows in flight are
+// a few M tiles' worth and stay in that XCD's 4 MB L2, instead of one M tile per workgroup.
+struct uavsal_tile_walk { int tile, end, stride; };
+#ifndef UAVSAL_TILE_WALK_STRIDED
+#define UAVSAL_TILE_WALK_STRIDED 1
+#endif
+__device__ __forceinline__ uavsal_tile_walk xcd_tile_walk(int bid, int G, int nblk) {
+    uavsal_tile_walk w;
+#if UAVSAL_TILE_WALK_STRIDED
+    const int q = G / UAVSAL_NUM_XCD, r = G % UAVSAL_NUM_XCD;
+    const int xcd = bid % UAVSAL_NUM_XCD, slot = bid / UAVSAL_NUM_XCD;
+    const int gx = q + (xcd < r ? 1 : 0);                         // workgroups on this XCD
+    const int vb0 = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const int t0 = (int)(((long long)vb0 * nblk) / G);
+    w.end = (int)(((long long)(vb0 + gx) * nblk) / G);
+    w.tile = t0 + slot;
+    w.stride = gx;
+#else
+    const int vb = xcd_virtual_block(bid, G);
+    w.tile = (int)(((long long)vb * nblk) / G);
+    w.end = (int)(((long long)(vb + 1) * nblk) / G);
+    w.stride = 1;
+#endif
+    return w;
+}
+
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == UAVSAL_ACT_RELU6) return fminf(fmaxf(v, 0.f), 6.f);
     if (act == UAVSAL_ACT_SIGMOID) return 1.f / (1.f + expf(-v));

@@ -250,16 +250,14 @@ void conv_gemm_kernel(const ConvK p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
-    // Persistent workgroups: the grid is sized to the resident capacity of the chip and every
-    // workgroup walks a contiguous range of output tiles (N fastest, so consecutive tiles
-    // re-read the same activation rows from L1/L2).  The virtual block id keeps each XCD on
-    // one contiguous range of tiles.  The first K tile of the NEXT output tile is requested
-    // before the epilogue of the current one, which hides the prologue's HBM/L2 latency --
-    // with K as short as 256 (16 K tiles) that latency was a third of the kernel's time.
-    const int G = gridDim.x;
-    const int vb = xcd_virtual_block(blockIdx.x, G);
-    int tile = (int)(((long long)vb * p.nblk) / G);
-    const int tile_end = (int)(((long long)(vb + 1) * p.nblk) / G);
+    // Persistent workgroups: the grid is sized to the resident capacity of the chip; every XCD owns a
+    // contiguous range of output tiles (N fastest) and its workgroups take them round-robin
+    // (common.h: xcd_tile_walk).  The loader below runs ahead across output-tile boundaries, which
+    // hides the prologue's HBM/L2 latency -- with K as short as 256 that latency was a third of the
+    // kernel's time.
+    const uavsal_tile_walk walk = xcd_tile_walk(blockIdx.x, gridDim.x, p.nblk);
+    int tile = walk.tile;
+    const int tile_end = walk.end, tile_step = walk.stride;
     if (tile >= tile_end) return;
     int m0 = 0, n0 = 0;
 
@@ -538,8 +536,8 @@ void conv_gemm_kernel(const ConvK p) {
         load_tile(l_kt, l_ci0, l_tapv, set);
         if (++l_s == S) {
             l_s = 0; lt_ci = 0; lt_tap = 0;
-            if (l_tile + 1 < tile_end) {         // past the last tile: keep re-requesting it (harmless)
-                ++l_tile;
+            if (l_tile + tile_step < tile_end) {  // past the last tile: keep re-requesting it (harmless)
+                l_tile += tile_step;
                 setup_tile(l_tile);
             }
         }
@@ -577,7 +575,8 @@ void conv_gemm_kernel(const ConvK p) {
 
         // ---- epilogue ------------------------------------------------------------------
         UAVSAL_GEMM_EPILOGUE((PREC == UAVSAL_PREC_F16X3 ? F16X3_ACC_SCALE : 1.0f), smem)
-        if (++tile >= tile_end) break;
+        tile += tile_step;
+        if (tile >= tile_end) break;
     }
 }
 
@@ -624,10 +623,9 @@ __global__ __launch_bounds__(256, (WM * WN >= 4) ? 3 : 4) void conv_gemm_f32_dma
 
     const int tid = threadIdx.x;
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform
-    const int G = gridDim.x;
-    const int vb = xcd_virtual_block(blockIdx.x, G);
-    int tile = (int)(((long long)vb * p.nblk) / G);
-    const int tile_end = (int)(((long long)(vb + 1) * p.nblk) / G);
+    const uavsal_tile_walk walk = xcd_tile_walk(blockIdx.x, gridDim.x, p.nblk);
+    int tile = walk.tile;
+    const int tile_end = walk.end, tile_step = walk.stride;
     if (tile >= tile_end) return;
     int m0 = 0, n0 = 0;
 
@@ -792,11 +790,11 @@ __global__ __launch_bounds__(256, (WM * WN >= 4) ? 3 : 4) void conv_gemm_f32_dma
             stage = (stage + 1 == S) ? 0 : stage + 1;
         }
 
-        const bool has_next = (tile + 1) < tile_end;
+        const bool has_next = (tile + tile_step) < tile_end;
         __builtin_amdgcn_s_barrier();            // every wave is done reading the ring (WAR: the
                                                  // next tile's DMA and the epilogue staging reuse it)
         if (has_next) {
-            ++tile;
+            tile += tile_step;
             setup_tile(tile);
             it_kt = 0; it_tap = 0; it_ci = 0;
             for (int t = 0; t < npre; ++t) issue_tile(t, t);
