@@ -52,10 +52,10 @@ def kernel_symbol(prec, tile, taps):
 
 def measured_traffic(symbol, C, T, H, W, prec):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950
-    note, + WRITE_SIZE; profiles/r1_hbm_traffic_f32_c1.json, collected for configs[1] only)."""
+    note, + WRITE_SIZE; profiles/r1_hbm_traffic_f32_c1_v2.json, collected for configs[1] only)."""
     if (C, T, H, W, prec) != (1, 8, 360, 640, "f32"):
         return None
-    path = os.path.join(ROOT, "profiles", "r1_hbm_traffic_f32_c1.json")
+    path = os.path.join(ROOT, "profiles", "r1_hbm_traffic_f32_c1_v2.json")
     if not os.path.exists(path):
         return None
     rec = json.load(open(path)).get(symbol)

@@ -530,8 +530,11 @@ void conv_gemm_kernel(const ConvK p) {
     auto loader_step = [&](int set) {
         if (l_s < p.ktiles) {
             l_kt = l_s; l_ci0 = lt_ci; l_tapv = lt_tap;
-            lt_ci += KT;
-            if (TAPS == 9 && lt_ci >= p.Cin) { lt_ci = 0; ++lt_tap; }
+            // 3x3: K runs channel-block-major, tap-minor -- the nine taps of one 64/128-byte channel
+            // chunk are nine consecutive K steps, so every fetched line sees all its uses while it
+            // is still in L2 (tap-major re-fetched the activations ~6x: PMC FETCH_SIZE)
+            if (TAPS == 9) { if (++lt_tap == 9) { lt_tap = 0; lt_ci += KT; } }
+            else lt_ci += KT;
         }
         load_tile(l_kt, l_ci0, l_tapv, set);
         if (++l_s == S) {
@@ -685,8 +688,8 @@ __global__ __launch_bounds__(256, (WM * WN >= 4) ? 3 : 4) void conv_gemm_f32_dma
                 dx = it_tap - ty * 3 - 1;
             }
             ++it_kt;
-            it_ci += KT;
-            if (TAPS == 9 && it_ci >= p.Cin) { it_ci = 0; ++it_tap; }
+            if (TAPS == 9) { if (++it_tap == 9) { it_tap = 0; it_ci += KT; } }   // channel block major, tap minor
+            else it_ci += KT;
 #pragma unroll
             for (int it = 0; it < A_IT; ++it) {
                 bool ok = a_ok[it] && kin;

@@ -47,7 +47,14 @@ def pack_conv_weight(w: torch.Tensor, prec: str) -> torch.Tensor:
     k = taps * cin
     kpad, npad = roundup(k, kt), roundup(cout, 32)
     m = torch.zeros(npad, kpad, dtype=torch.float32)
-    m[:cout, :k] = w.permute(0, 2, 3, 1).reshape(cout, k)        # k = tap*Cin + ci
+    if taps == 1:
+        m[:cout, :k] = w.reshape(cout, k)
+    else:
+        # 3x3: channel-block-major, tap-minor: k = ((ci // kt) * 9 + tap) * kt + ci % kt, so the nine taps
+        # of one channel chunk are nine consecutive K steps (activation lines are reused while in L2)
+        if cin % kt:
+            raise RuntimeError("3x3 dense conv needs Cin %% %d == 0" % kt)
+        m[:cout, :k] = w.reshape(cout, cin // kt, kt, 9).permute(0, 1, 3, 2).reshape(cout, k)
     if prec == "f32":
         return m.contiguous().view(torch.uint8).reshape(-1)
     # 16-bit layouts are K-step-major: [Kpad/32][panel][Npad][32] -- one K step is one contiguous run

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define UAVSAL_ABI_VERSION 5
+#define UAVSAL_ABI_VERSION 6
 
 /* argument errors */
 #define UAVSAL_EINVAL   (-1)  /* null pointer / non-positive size */
@@ -86,7 +86,9 @@ typedef void* uavsal_stream_t;
  *             h_t = sigmoid(z_o)*tanh(c_t).   Runs on the 64x64 tile; needs 16-byte aligned ld's.
  *
  * Weights `w` are pre-packed by the host (iip_uavsal_saliency_amd/packing.py):
- *   k index = tap * Cin + ci, rows padded to Npad = roundup(Cout, 32), K padded to
+ *   k index = ci for taps == 1; for taps == 9 (tap = ky*3 + kx) channel-block-major, tap-minor:
+ *   k = ((ci / KT) * 9 + tap) * KT + ci % KT, so that the nine taps of one channel chunk are
+ *   nine consecutive K steps; rows padded to Npad = roundup(Cout, 32), K padded to
  *   Kpad = roundup(taps * Cin, KT) with zeros, KT = 16 (F32) or 32 (BF16*, F16X3);
  *   F32:    float  [Npad][Kpad]
  *   The 16-bit layouts are K-step-major, so that the weight rows one K step needs are ONE

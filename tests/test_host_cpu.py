@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert declared == bound, (declared ^ bound)
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.uavsal_abi_version() == 5
+    assert lib.uavsal_abi_version() == 6
     assert b"gfx950" in lib.uavsal_build_info()
 
 
@@ -77,11 +77,18 @@ def test_pack_conv_weight_layouts(shape):
     w = torch.rand(shape, generator=g) - 0.5
     cout, cin, kh, _ = shape
     k = cin * kh * kh
-    ref = w.permute(0, 2, 3, 1).reshape(cout, k)                 # k = tap*Cin + ci
+
+    def k_order(kt):     # 1x1: k = ci; 3x3: k = ((ci // kt) * 9 + tap) * kt + ci % kt  (uavsal_hip.h)
+        if kh == 1:
+            return w.reshape(cout, k)
+        return w.reshape(cout, cin // kt, kt, 9).permute(0, 1, 3, 2).reshape(cout, k)
+
+    ref = k_order(16)
     f = P.pack_conv_weight(w, "f32").view(torch.float32)
     npad, kpad = P.roundup(cout, 32), P.roundup(k, 16)
     f = f.view(npad, kpad)
     assert torch.equal(f[:cout, :k], ref) and f[cout:].abs().sum() == 0 and f[:, k:].abs().sum() == 0
+    ref = k_order(32)
     kpad = P.roundup(k, 32)
     inv = torch.empty(32, dtype=torch.long)
     inv[torch.tensor(P._K_PERM32)] = torch.arange(32)
