@@ -634,8 +634,8 @@ __global__ __launch_bounds__(256, (WM * WN >= 4) ? 3 : 4) void conv_gemm_f32_dma
 
     // per-thread DMA coordinates: row (tid>>2) + it*64 of the tile, physical chunk tid&3
     const int pc = tid & 3;
-    long long a_base[A_IT];
-    int a_y[A_IT], a_x[A_IT], a_lc[A_IT];
+    long long a_base[A_IT];          // element offset of the row's centre pixel
+    int a_taps[A_IT], a_lc[A_IT];    // 3x3: bit t set = tap t of this row lies inside the image
     bool a_ok[A_IT];
     int b_lc[B_IT];
     const float* zero = g_zero16;
@@ -653,13 +653,21 @@ __global__ __launch_bounds__(256, (WM * WN >= 4) ? 3 : 4) void conv_gemm_f32_dma
             const int mm = a_ok[it] ? m : 0;
             if (TAPS == 1) {
                 a_base[it] = row_off(mm, p.HW, p.a_is, p.contig) * p.lda;
-                a_y[it] = 0; a_x[it] = 0;
+                a_taps[it] = 0;
             } else {
+                // per step only a wave-uniform tap delta is added and one mask bit tested: the DMA
+                // issue path is what bounds this kernel, so no per-step bounds arithmetic
                 const int img = mm / p.HW;
                 const int pix = mm - img * p.HW;
-                a_y[it] = pix / p.W;
-                a_x[it] = pix - a_y[it] * p.W;
-                a_base[it] = (long long)img * p.a_is;
+                const int y = pix / p.W, x = pix - y * p.W;
+                a_base[it] = ((long long)img * p.a_is + pix) * p.lda;
+                int mask = 0;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+                    if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) mask |= 1 << t;
+                }
+                a_taps[it] = mask;
             }
         }
 #pragma unroll
@@ -681,11 +689,11 @@ __global__ __launch_bounds__(256, (WM * WN >= 4) ? 3 : 4) void conv_gemm_f32_dma
             char* As = smem + stage * STAGE + q * PANEL;
             char* Bs = As + APAN;
             const int ci0 = it_ci;
-            int dy = 0, dx = 0;
+            const int tap = it_tap;
+            long long tap_off = 0;                          // wave-uniform: (dy * W + dx) * lda
             if (TAPS == 9) {
-                const int ty = (it_tap * 11) >> 5;          // tap / 3 for tap in 0..9
-                dy = ty - 1;
-                dx = it_tap - ty * 3 - 1;
+                const int ty = (tap * 11) >> 5;             // tap / 3 for tap in 0..9
+                tap_off = (long long)((ty - 1) * p.W + (tap - ty * 3 - 1)) * p.lda;
             }
             ++it_kt;
             if (TAPS == 9) { if (++it_tap == 9) { it_tap = 0; it_ci += KT; } }   // channel block major, tap minor
@@ -693,14 +701,8 @@ __global__ __launch_bounds__(256, (WM * WN >= 4) ? 3 : 4) void conv_gemm_f32_dma
 #pragma unroll
             for (int it = 0; it < A_IT; ++it) {
                 bool ok = a_ok[it] && kin;
-                long long off;
-                if (TAPS == 1) {
-                    off = a_base[it];
-                } else {
-                    const int yy = a_y[it] + dy, xx = a_x[it] + dx;
-                    ok = ok && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
-                    off = (a_base[it] + (long long)yy * p.W + xx) * p.lda;
-                }
+                if (TAPS == 9) ok = ok && ((a_taps[it] >> tap) & 1);
+                const long long off = a_base[it] + tap_off;
                 const int kk = ci0 + a_lc[it] * 4;
                 const float* src = (ok && kk < p.Cin) ? (p.a + off + kk) : zero;
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + (it * 64 + wave_u * 16) * 64), 16, 0, 0);
