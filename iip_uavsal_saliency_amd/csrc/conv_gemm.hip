@@ -267,7 +267,8 @@ void conv_gemm_kernel(const ConvK p) {
     constexpr int ESZ = (PREC == UAVSAL_PREC_F32) ? 4 : 2;
     const int b_row0 = stid >> 2;
     long long a_base[A_IT];
-    int a_y[A_IT], a_x[A_IT];
+    int a_y[A_IT], a_x[A_IT];            // fused producer only
+    int a_taps[A_IT];                    // 3x3: bit t set = tap t of this row lies inside the image
     bool a_ok[A_IT];
     unsigned b_off[B_IT];
     auto setup_tile = [&](int t) {
@@ -281,9 +282,25 @@ void conv_gemm_kernel(const ConvK p) {
             const int m = m0 + row;
             a_ok[it] = m < p.M;
             const int mm = a_ok[it] ? m : 0;
+            a_taps[it] = 0;
             if (TAPS == 1 && !FUSE) {
                 a_base[it] = row_off(mm, p.HW, p.a_is, p.contig) * p.lda;
                 a_y[it] = 0; a_x[it] = 0;
+            } else if (TAPS == 9) {
+                // element offset of the centre pixel + a mask of the taps inside the image: per K step
+                // only a wave-uniform tap delta is added and one bit tested
+                const int img = mm / p.HW;
+                const int pix = mm - img * p.HW;
+                const int y = pix / p.W, x = pix - y * p.W;
+                a_base[it] = ((long long)img * p.a_is + pix) * p.lda;
+                a_y[it] = 0; a_x[it] = 0;
+                int mask = 0;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+                    if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) mask |= 1 << t;
+                }
+                a_taps[it] = mask;
             } else {
                 const int img = mm / p.HW;
                 const int pix = mm - img * p.HW;
@@ -316,11 +333,10 @@ void conv_gemm_kernel(const ConvK p) {
     u32x4 b_reg[D][B_IT][NPAN];
 
     auto load_tile = [&](int kt, int ci0, int tap, int set) {
-        int dy = 0, dx = 0;
+        long long tap_off = 0;                              // wave-uniform: (dy * W + dx) * lda
         if (TAPS == 9) {
             const int ty = (tap * 11) >> 5;                 // tap / 3 for tap in 0..9
-            dy = ty - 1;
-            dx = tap - ty * 3 - 1;
+            tap_off = (long long)((ty - 1) * p.W + (tap - ty * 3 - 1)) * p.lda;
         }
         if (FUSE) {
             // depthwise 3x3 (+BN+ReLU6) of E for this thread's rows and 4-channel groups
@@ -362,14 +378,8 @@ void conv_gemm_kernel(const ConvK p) {
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             bool ok = a_ok[it];
-            long long off;
-            if (TAPS == 1) {
-                off = a_base[it];
-            } else {
-                const int yy = a_y[it] + dy, xx = a_x[it] + dx;
-                ok = ok && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
-                off = (a_base[it] + (long long)yy * p.W + xx) * p.lda;
-            }
+            if (TAPS == 9) ok = ok && ((a_taps[it] >> tap) & 1);
+            const long long off = a_base[it] + tap_off;
 #pragma unroll
             for (int l = 0; l < NLD; ++l) {
                 const int kk = ci0 + ch * 4 + l * 16;
