@@ -200,5 +200,7 @@ extern "C" int uavsal_sizeof_desc(int which) {
 }
 
 extern "C" const char* uavsal_build_info(void) {
-    return "libuavsal_hip gfx950 abi " "4" " (" __DATE__ " " __TIME__ ")";
+#define UAVSAL_STR2(x) #x
+#define UAVSAL_STR(x) UAVSAL_STR2(x)
+    return "libuavsal_hip gfx950 abi " UAVSAL_STR(UAVSAL_ABI_VERSION) " (" __DATE__ " " __TIME__ ")";
 }
