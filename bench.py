@@ -166,6 +166,7 @@ def main():
                     "than the native launch loop on ROCm 7.2: 1227-1247 vs 1268-1288 frames/s)")
     ap.add_argument("--lanes", type=int, default=1, help="run independent branches on parallel streams / graph branches")
     ap.add_argument("--fuse-dw", type=int, default=-1, help="-1 engine default, 0/1 force the fused depthwise->projection GEMM")
+    ap.add_argument("--stream-k", type=int, default=1, help="fp32 GEMMs: stream-K when whole tiles would idle CUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
@@ -197,6 +198,7 @@ def main():
     model.use_graph = bool(args.graph)
     model.fuse_dw = None if args.fuse_dw < 0 else bool(args.fuse_dw)
     model.use_lanes = bool(args.lanes)
+    model.stream_k = bool(args.stream_k)
 
     x_cpu, cb_cpu = make_clips(C, T, H, W, seed=shard.first)       # this rank's clips
     x = x_cpu.to(device)

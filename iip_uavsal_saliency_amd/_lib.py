@@ -34,7 +34,8 @@ class ConvDesc(C.Structure):
                 ("prec", C.c_int32), ("act", C.c_int32), ("epi", C.c_int32), ("tile", C.c_int32),
                 ("out2", _f), ("ld2", C.c_int32),
                 ("dw_w9c", _f), ("dw_scale", _f), ("dw_bias", _f),
-                ("dw_stride", C.c_int32), ("dw_Hin", C.c_int32), ("dw_Win", C.c_int32)]
+                ("dw_stride", C.c_int32), ("dw_Hin", C.c_int32), ("dw_Win", C.c_int32),
+                ("sk_ws", _f), ("sk_ws_bytes", C.c_int64)]
 
 
 class DwDesc(C.Structure):
@@ -83,6 +84,7 @@ DESC_TYPES = [ConvDesc, DwDesc, StemDesc, BilinearDesc, TdiffDesc, TsumDesc, Lay
 SYMBOLS = [
     ("uavsal_conv_gemm", C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     ("uavsal_conv_tile", C.c_int, [C.POINTER(ConvDesc)]),
+    ("uavsal_streamk_workspace_bytes", C.c_longlong, []),
     ("uavsal_dw3x3", C.c_int, [C.POINTER(DwDesc), C.c_void_p]),
     ("uavsal_stem_conv", C.c_int, [C.POINTER(StemDesc), C.c_void_p]),
     ("uavsal_bilinear_ac", C.c_int, [C.POINTER(BilinearDesc), C.c_void_p]),
@@ -130,7 +132,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.uavsal_abi_version() != 6:
+    if lib.uavsal_abi_version() != 7:
         raise RuntimeError("libuavsal_hip.so ABI version mismatch")
     for i, t in enumerate(DESC_TYPES):
         if lib.uavsal_sizeof_desc(i) != C.sizeof(t):

@@ -48,6 +48,8 @@ struct ConvK {
     int lda, ldc, ldr, ldx, ld2;
     int M, HW, H, W, Cin, Cout, Kpad, Npad, ktiles, act, epi;
     int tiles_n, nblk, contig;
+    float* sk_part;      // stream-K: one BM x BN fp32 partial per workgroup ...
+    int* sk_flag;        // ... and its "published" flag (0 at launch, reset by the consumer)
 };
 
 __device__ __forceinline__ long long row_off(int m, int HW, long long img_stride, int contig) {
@@ -221,6 +223,9 @@ __device__ __forceinline__ f32x4 prescale(f32x4 x) {
 // being masked off
 __device__ __attribute__((aligned(16))) float g_zero16[4];
 
+#ifndef UAVSAL_SK_PREFETCH
+#define UAVSAL_SK_PREFETCH 1
+#endif
 #ifndef UAVSAL_GEMM_PREFETCH
 #define UAVSAL_GEMM_PREFETCH 2
 #endif
@@ -611,8 +616,16 @@ void conv_gemm_kernel(const ConvK p) {
 // being masked off (a masked lane would leave stale LDS behind).
 
 
-template <int WAVES_M, int WAVES_N, int WM, int WN, int TAPS, int S, int NKP>
-__global__ __launch_bounds__(256, (WM * WN >= 4) ? 3 : 4) void conv_gemm_f32_dma_kernel(const ConvK p) {
+// SK = true (stream-K): the K stages of an XCD's tiles form one line that is cut into equal
+// ranges, one per workgroup, so every CU gets the same number of MFMA stages even when there are
+// only 1.76 tiles per CU (one clip: 450 tiles of the K=1536 projections and of the 3x3 convs, where
+// whole-tile scheduling idles 12-15 % of the chip).  A range is [tail piece of a tile][whole
+// tiles][head piece of a tile].  A tail piece is computed FIRST and published (fp32 partial +
+// flag, device-coherent accesses); the workgroup that owns a tile's first stage computes its head
+// piece LAST, adds the published pieces in a fixed order and runs the epilogue -- nobody waits
+// on work that has not been started, and the summation order is fixed by the grid.
+template <int WAVES_M, int WAVES_N, int WM, int WN, int TAPS, int S, int NKP, bool SK = false>
+__global__ __launch_bounds__(256, SK ? 2 : ((WM * WN >= 4) ? 3 : 4)) void conv_gemm_f32_dma_kernel(const ConvK p) {
     constexpr int BM = WAVES_M * WM * 32;
     constexpr int BN = WAVES_N * WN * 32;
     constexpr int KT = 16;                       // one 64-byte panel row; a stage holds NKP panels
@@ -639,7 +652,7 @@ __global__ __launch_bounds__(256, (WM * WN >= 4) ? 3 : 4) void conv_gemm_f32_dma
     const uavsal_tile_walk walk = xcd_tile_walk(blockIdx.x, gridDim.x, p.nblk);
     int tile = walk.tile;
     const int tile_end = walk.end, tile_step = walk.stride;
-    if (tile >= tile_end) return;
+    if (!SK && tile >= tile_end) return;
     int m0 = 0, n0 = 0;
 
     // per-thread DMA coordinates: row (tid>>2) + it*64 of the tile, physical chunk tid&3
@@ -781,8 +794,128 @@ __global__ __launch_bounds__(256, (WM * WN >= 4) ? 3 : 4) void conv_gemm_f32_dma
         }
     };
 
-    setup_tile(tile);
     const int nst = (kpanels + NKP - 1) / NKP;   // stages (groups of NKP panels) along K
+    if constexpr (SK) {
+        // ---- this XCD's tiles and this workgroup's range of their K stages -------------------
+        const int G = gridDim.x, q = G / UAVSAL_NUM_XCD, r = G % UAVSAL_NUM_XCD;
+        const int xcd = blockIdx.x % UAVSAL_NUM_XCD, slot = blockIdx.x / UAVSAL_NUM_XCD;
+        const int gx = q + (xcd < r ? 1 : 0);
+        const int vb0 = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        const int T0 = (int)(((long long)vb0 * p.nblk) / G);
+        const int T1 = (int)(((long long)(vb0 + gx) * p.nblk) / G);
+        const long long Wx = (long long)(T1 - T0) * nst;
+        auto bound = [&](int j) { return (int)((Wx * j) / gx); };     // first stage of workgroup j
+        int cur = bound(slot);
+        const int w1 = bound(slot + 1);
+        const int lane_idx = tid;                                     // partials are stored in register order
+        struct Seg { int tl, s_begin, nseg, npre, m0c, n0c; };
+        // opens the segment that starts at stage `c` of the XCD's line: tile coordinates, K position,
+        // and the first D stages requested
+        auto open_segment = [&](int c) {
+            Seg g;
+            g.tl = c / nst;
+            g.s_begin = c - g.tl * nst;
+            g.nseg = min(nst - g.s_begin, w1 - c);
+            tile = T0 + g.tl;
+            setup_tile(tile);
+            g.m0c = m0; g.n0c = n0;
+            it_kt = g.s_begin * NKP;
+            if (TAPS == 9) { it_tap = it_kt % 9; it_ci = (it_kt / 9) * KT; }
+            else { it_tap = 0; it_ci = it_kt * KT; }
+            g.npre = g.nseg < D ? g.nseg : D;
+            for (int t = 0; t < g.npre; ++t) issue_tile(t, t);
+            return g;
+        };
+        Seg sg = {};
+        if (cur < w1) sg = open_segment(cur);
+        while (cur < w1) {
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
+            int stage = 0, istage = sg.npre % S;
+            for (int kt = 0; kt < sg.nseg; ++kt) {
+                if (kt + D <= sg.nseg) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LPT * (D - 1)) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                const bool do_issue = kt + D < sg.nseg;
+                compute(stage, do_issue, istage);
+                if (do_issue) istage = (istage + 1 == S) ? 0 : istage + 1;
+                stage = (stage + 1 == S) ? 0 : stage + 1;
+            }
+            __builtin_amdgcn_s_barrier();        // ring reads done: stages 0..D-1 take the next segment's
+                                                 // first requests, stage S-1 the epilogue staging
+            const int tl = sg.tl, s_begin = sg.s_begin, m0c = sg.m0c, n0c = sg.n0c;
+            cur += sg.nseg;
+#if UAVSAL_SK_PREFETCH
+            if (cur < w1) sg = open_segment(cur);    // lands while this segment is published / finished
+#endif
+            if (s_begin > 0) {
+                // a later piece of a tile whose first stage belongs to another workgroup: publish
+                float* part = p.sk_part + (size_t)(vb0 + slot) * (BM * BN);
+                // device-coherent (sc1) 16-byte stores: dword stores at agent scope move these 64 KB at a
+                // fraction of the rate and put ~30 us on the critical path of a 230 us launch
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j)
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; ++q4) {
+                            const f32x4 v = {acc[i][j][4 * q4], acc[i][j][4 * q4 + 1], acc[i][j][4 * q4 + 2],
+                                             acc[i][j][4 * q4 + 3]};
+                            float* dst = part + ((size_t)((i * WN + j) * 4 + q4) * 256 + lane_idx) * 4;
+                            asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(v) : "memory");
+                        }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) __hip_atomic_store(p.sk_flag + vb0 + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                // owner of the tile's first stage: add the pieces the following workgroups published
+                int e = cur, k = slot + 1;
+                while (e < (tl + 1) * nst) {
+                    if (tid == 0) {
+                        int spins = 0;       // bounded: a lost piece must never hang the GPU
+                        while (__hip_atomic_load(p.sk_flag + vb0 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 &&
+                               ++spins < (1 << 22))
+                            __builtin_amdgcn_s_sleep(8);
+                        if (spins >= (1 << 22)) __hip_atomic_store(p.sk_flag + G, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    __syncthreads();
+                    const float* part = p.sk_part + (size_t)(vb0 + k) * (BM * BN);
+#pragma unroll
+                    for (int i = 0; i < WM; ++i) {
+                        f32x4 t[WN * 4];
+#pragma unroll
+                        for (int n = 0; n < WN * 4; ++n) {
+                            const float* src = part + ((size_t)(i * WN * 4 + n) * 256 + lane_idx) * 4;
+                            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(t[n]) : "v"(src) : "memory");
+                        }
+                        static_assert(WN * 4 == 8, "the wait below names eight registers");
+                        // the loads are invisible to the compiler's waitcnt pass: tie the results to the wait
+                        asm volatile("s_waitcnt vmcnt(0)"
+                                     : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]),
+                                       "+v"(t[6]), "+v"(t[7]) :: "memory");
+#pragma unroll
+                        for (int n = 0; n < WN * 4; ++n)
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) acc[i][n >> 2][4 * (n & 3) + c] += t[n][c];
+                    }
+                    __syncthreads();
+                    if (tid == 0) __hip_atomic_store(p.sk_flag + vb0 + k, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    e = bound(k + 1);
+                    ++k;
+                }
+                UAVSAL_GEMM_EPILOGUE(1.0f, (smem + (S - 1) * STAGE))
+            }
+#if !UAVSAL_SK_PREFETCH
+            if (cur < w1) sg = open_segment(cur);
+#endif
+        }
+        return;
+    }
+    setup_tile(tile);
     const int npre = nst < D ? nst : D;
     for (int t = 0; t < npre; ++t) issue_tile(t, t);
     while (true) {
@@ -857,6 +990,28 @@ int launch_variant(const ConvK& k0, int taps, hipStream_t stream) {
         const int grid = k.nblk < cap ? k.nblk : cap;
         hipLaunchKernelGGL((conv_gemm_kernel<PREC, WAVES_M, WAVES_N, WM, WN, 9>), dim3(grid), dim3(NT), SMEM, stream, k);
     }
+    return uavsal_launch_status();
+}
+
+// stream-K is used for the 128 x 128 fp32 tile when whole-tile scheduling would leave part of the
+// chip idle in the last round; grid = 2 workgroups per CU (measured best for these shapes)
+static inline int streamk_grid(long long nblk, int kstages, int cus) {
+    const int G = 2 * cus;
+    // each range covers >= half a tile; short K loops lose more to publishing / collecting the 64 KB
+    // partial tiles than they win (K=256: 48 -> 68 us), long ones win 2-40 % (profiles/r1_streamk_probe.log)
+    if (nblk < G / 2 + 1 || nblk >= 3LL * cus * 3 || kstages < 48 || nblk % G == 0) return 0;
+    const long long per_cu3 = (nblk + 3LL * cus - 1) / (3LL * cus);           // rounds at 3 workgroups per CU
+    const double eff = (double)nblk / (double)(per_cu3 * 3 * cus);
+    return eff < 0.93 ? G : 0;
+}
+
+template <int TAPS>
+int launch_f32_streamk(const ConvK& k0, int G, hipStream_t stream) {
+    constexpr int SMEM = 3 * (128 + 128) * 64;
+    ConvK k = k0;
+    k.tiles_n = (k.Cout + 127) / 128;
+    k.nblk = ((k.M + 127) / 128) * k.tiles_n;
+    hipLaunchKernelGGL((conv_gemm_f32_dma_kernel<2, 2, 2, 2, TAPS, 3, 1, true>), dim3(G), dim3(256), SMEM, stream, k);
     return uavsal_launch_status();
 }
 
@@ -935,6 +1090,14 @@ int pick_tile(long long M, int Cout, int prec) {
 
 }  // namespace
 
+extern "C" long long uavsal_streamk_workspace_bytes(void) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    const long long G = 2LL * n;
+    return G * 128 * 128 * 4 + (G + 1) * 4;
+}
+
 extern "C" int uavsal_conv_tile(const uavsal_conv_desc* d) {
     if (!d || d->n_img <= 0 || d->H <= 0 || d->W <= 0 || d->Cout <= 0) return UAVSAL_EINVAL;
     if (d->epi == UAVSAL_EPI_LSTM) return 4;
@@ -994,6 +1157,7 @@ extern "C" int uavsal_conv_gemm(const uavsal_conv_desc* d, uavsal_stream_t strea
     k.act = d->act; k.epi = d->epi;
     k.contig = ((k.a_is == HW || k.dw_w) && k.o_is == HW && k.r_is == HW && k.x_is == HW) ? 1 : 0;
     k.tiles_n = 0; k.nblk = 0;
+    k.sk_part = nullptr; k.sk_flag = nullptr;
     int tile = (d->tile >= 1 && d->tile <= 6) ? d->tile : pick_tile(M, d->Cout, d->prec);
     if (tile == 6) {   // the 256 x 256 tile only carries the vector epilogue
         const bool vec = d->epi == UAVSAL_EPI_AFFINE && d->act != UAVSAL_ACT_SIGMOID && !(d->ldc & 3) &&
@@ -1003,6 +1167,22 @@ extern "C" int uavsal_conv_gemm(const uavsal_conv_desc* d, uavsal_stream_t strea
     }
     if (d->epi == UAVSAL_EPI_LSTM) tile = 4;     // the LSTM update lives in the 64x64 tile's vector epilogue
     hipStream_t s = (hipStream_t)stream;
+    if (d->prec == UAVSAL_PREC_F32 && tile == 1 && !k.dw_w && d->sk_ws && uavsal_aligned16(d->sk_ws)) {
+        static const int cus = [] {
+            int dev = 0, n = 0;
+            if (hipGetDevice(&dev) != hipSuccess ||
+                hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+            return n;
+        }();
+        const long long nblk = ((M + 127) / 128) * ((d->Cout + 127) / 128);
+        const int G = streamk_grid(nblk, k.ktiles, cus);
+        const long long need = (long long)G * 128 * 128 * 4 + (long long)(G + 1) * 4;
+        if (G > 0 && d->sk_ws_bytes >= need) {
+            k.sk_part = (float*)d->sk_ws;
+            k.sk_flag = (int*)((char*)d->sk_ws + (long long)G * 128 * 128 * 4);
+            return d->taps == 1 ? launch_f32_streamk<1>(k, G, s) : launch_f32_streamk<9>(k, G, s);
+        }
+    }
     switch (d->prec) {
         case UAVSAL_PREC_F32:    // the fused producer needs register staging: use the generic kernel
             return k.dw_w ? launch_prec<UAVSAL_PREC_F32>(k, d->taps, tile, s) : launch_f32(k, d->taps, tile, s);

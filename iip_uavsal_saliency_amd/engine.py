@@ -53,7 +53,7 @@ class V:
 class Engine:
     def __init__(self, model, device, n_seq, seq_len, H, W, ctx_T, ctx_mode="tile",
                  precision="f32", taps=False, in_dtype=torch.float32, use_graph=False, fuse_dw=None,
-                 use_lanes=True):
+                 use_lanes=True, stream_k=True):
         if precision not in L.PREC:
             raise ValueError("precision must be one of %s" % list(L.PREC))
         self.lib = L.load()
@@ -68,6 +68,8 @@ class Engine:
         self.keep_taps = taps
         self.in_dtype = in_dtype
         self.use_graph = use_graph
+        self.stream_k = bool(stream_k)
+        self._sk_ws = None
         # fused depthwise->projection GEMM (uavsal_conv_desc.dw_*): D never reaches HBM.
         # Measured (profiles/README.md): as written -- nine dependent global loads per staged value, no
         # LDS-staged halo tile -- the fused loader is latency-bound and ~1.5x SLOWER end to end, so it is
@@ -240,6 +242,12 @@ class Engine:
         d.prec, d.act, d.epi, d.tile = self.prec, act, epi, 0
         if out2 is not None:
             d.out2, d.ld2 = out2.ptr, out2.ld
+        if self.stream_k and self._lane == 0:
+            # one workspace: launches on lane 0 are ordered on one stream (uavsal_conv_desc.sk_ws)
+            if self._sk_ws is None:
+                self._sk_ws = torch.zeros(int(self.lib.uavsal_streamk_workspace_bytes()), dtype=torch.uint8,
+                                          device=self.device)
+            d.sk_ws, d.sk_ws_bytes = self._sk_ws.data_ptr(), self._sk_ws.numel()
         self.ops_meta[-1]["tile"] = int(self.lib.uavsal_conv_tile(C.byref(d)))
         self._add(self.lib.uavsal_plan_add_conv, d, "plan_add_conv(%s)" % name)
 

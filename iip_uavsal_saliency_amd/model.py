@@ -164,6 +164,7 @@ class UAVSal(nn.Module):
         self.use_graph = False          # replay the launch plan as one hipGraph
         self.fuse_dw = None             # None: engine default (off; see engine.py)
         self.use_lanes = True           # independent branches on parallel streams / graph branches
+        self.stream_k = True            # fp32 GEMMs: split K across workgroups when whole tiles leave CUs idle
         self.sfnet = uavsal_srfnet_aspp(cnn_type, last_channel=planes)
         self.num_stblock = num_stblock
         self.st_layer = nn.Sequential(*[
@@ -215,13 +216,14 @@ class UAVSal(nn.Module):
     def _engine(self, device, n_seq, seq_len, H, W, ctx_mode, taps=False, in_dtype=torch.float32):
         from .engine import Engine
         key = (str(device), n_seq, seq_len, H, W, self.time_dims if ctx_mode == "tile" else seq_len,
-               ctx_mode, self.precision, bool(taps), in_dtype, bool(self.use_graph), self.rnn_type, self.fuse_dw, bool(self.use_lanes))
+               ctx_mode, self.precision, bool(taps), in_dtype, bool(self.use_graph), self.rnn_type, self.fuse_dw, bool(self.use_lanes),
+               bool(self.stream_k))
         eng = self._engines.get(key)
         if eng is None:
             eng = Engine(self, device, n_seq=n_seq, seq_len=seq_len, H=H, W=W,
                          ctx_T=key[5], ctx_mode=ctx_mode, precision=self.precision, taps=taps,
                          in_dtype=in_dtype, use_graph=self.use_graph, fuse_dw=self.fuse_dw,
-                         use_lanes=self.use_lanes)
+                         use_lanes=self.use_lanes, stream_k=self.stream_k)
             self._engines[key] = eng
         return eng
 

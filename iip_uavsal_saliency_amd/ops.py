@@ -32,7 +32,8 @@ def _nhwc_view(t: torch.Tensor):
     return t.data_ptr(), ld, n, h, w, c
 
 
-def conv_gemm(x, weight, scale=None, bias=None, act=L.ACT_NONE, res=None, out=None, prec="f32", tile=0, dw=None):
+def conv_gemm(x, weight, scale=None, bias=None, act=L.ACT_NONE, res=None, out=None, prec="f32", tile=0, dw=None,
+              stream_k=False):
     """Dense 1x1 / 3x3 conv (+ folded BN, activation, residual).  `weight` [Cout,Cin,k,k] (cpu or cuda).
     `dw=(w[C,1,3,3], scale[C], bias[C], stride)`: x is the expanded tensor and the depthwise 3x3 + BN + ReLU6
     in front of this 1x1 conv is computed inside the GEMM's loader (fused inverted-residual tail)."""
@@ -67,8 +68,18 @@ def conv_gemm(x, weight, scale=None, bias=None, act=L.ACT_NONE, res=None, out=No
         d.res, d.ldr, d.r_img_stride = rp, ldr, h * w
     d.n_img, d.H, d.W, d.Cin, d.Cout, d.taps = n, h, w, cin, cout, taps
     d.prec, d.act, d.epi, d.tile = L.PREC[prec], act, L.EPI_AFFINE, tile
+    if stream_k:
+        ws = torch.zeros(int(lib.uavsal_streamk_workspace_bytes()), dtype=torch.uint8, device=x.device)
+        keep.append(ws)
+        d.sk_ws, d.sk_ws_bytes = ws.data_ptr(), ws.numel()
     L.check(lib.uavsal_conv_gemm(C.byref(d), _stream(x)), "uavsal_conv_gemm")
     torch.cuda.current_stream(x.device).synchronize()   # `keep` must outlive the launch
+    if stream_k:
+        # the kernels leave the workspace zeroed; a set word means a published piece was never consumed,
+        # or the bounded wait for one gave up
+        g = (ws.numel() - 4) // (128 * 128 * 4 + 4)          # [g partial tiles][g flags + 1 timeout word]
+        if int(ws.view(torch.int32)[-(g + 1):].abs().sum().item()) != 0:
+            raise RuntimeError("stream-K workspace not clean after the launch")
     return out
 
 

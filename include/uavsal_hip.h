@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define UAVSAL_ABI_VERSION 6
+#define UAVSAL_ABI_VERSION 7
 
 /* argument errors */
 #define UAVSAL_EINVAL   (-1)  /* null pointer / non-positive size */
@@ -122,11 +122,19 @@ typedef struct uavsal_conv_desc {
      * dw_w9c is tap-major [9][Cin] as in uavsal_dw_desc; a_img_stride counts input pixels. */
     const float* dw_w9c; const float* dw_scale; const float* dw_bias;
     int32_t dw_stride, dw_Hin, dw_Win;
+    /* Optional stream-K workspace (fp32, 128x128 tile): `uavsal_streamk_workspace_bytes()` bytes of device
+     * memory, 16-byte aligned, ZERO-filled once by the caller and then owned by launches that are ordered
+     * on one stream (the kernels leave it zeroed).  With it, launches whose tile count would idle part of
+     * the chip in the last round split the K loop of some tiles across workgroups; the summation order
+     * stays a function of the shape only.  NULL = whole-tile scheduling. */
+    void* sk_ws; int64_t sk_ws_bytes;
 } uavsal_conv_desc;
 
 int uavsal_conv_gemm(const uavsal_conv_desc* d, uavsal_stream_t stream);
 /* block tile `uavsal_conv_gemm` will use for this descriptor (1..6, see `tile`); no launch */
 int uavsal_conv_tile(const uavsal_conv_desc* d);
+/* size of the optional stream-K workspace (see uavsal_conv_desc.sk_ws) */
+long long uavsal_streamk_workspace_bytes(void);
 
 /*
  * Depthwise 3x3 convolution + folded BatchNorm + ReLU6, NHWC, stride 1 or 2,

@@ -113,6 +113,31 @@ def test_conv_wide_tile(ops, prec, case, tile):
     assert err <= TOL[prec] * 4.0, (case, prec, err)
 
 
+@pytest.mark.parametrize("case", [(8, 45, 80, 1536, 256, 1, True),     # 450 tiles, 96 K stages: the projections
+                                  (8, 45, 80, 448, 256, 9, False),     # 450 tiles, 3x3 (conv_last)
+                                  (8, 45, 80, 768, 256, 1, True),      # 450 tiles, 48 K stages (the shortest taken)
+                                  (8, 45, 80, 800, 768, 1, False),     # 1350 tiles: ranges of 2.6 tiles
+                                  (5, 45, 80, 1024, 256, 1, False),    # 282 tiles: ranges of 0.55 tile (3 pieces)
+                                  (8, 45, 80, 256, 256, 1, True)])     # short K: stays whole-tile
+def test_conv_stream_k(ops, case):
+    """fp32 128x128 GEMM with the stream-K workspace: tiles whose K loop is split across workgroups must
+    give the whole-tile result (up to fp32 summation order) and leave the workspace zeroed."""
+    n, h, w, cin, cout, taps, use_res = case
+    x = rnd((n, cin, h, w), 81, 2.0)
+    k = 3 if taps == 9 else 1
+    wt = rnd((cout, cin, k, k), 82, 1.0 / (cin * taps) ** 0.5)
+    scale, bias = rnd((cout,), 83, 0.5) + 1.0, rnd((cout,), 84, 0.1)
+    res = rnd((n, cout, h, w), 85, 1.0)
+    xd, rd = nhwc(x), nhwc(res) if use_res else None
+    whole = ops.conv_gemm(xd, wt, scale, bias, act=1, res=rd, prec="f32", tile=1)
+    split = ops.conv_gemm(xd, wt, scale, bias, act=1, res=rd, prec="f32", tile=1, stream_k=True)
+    assert (split - whole).abs().max().item() <= TOL["f32"] * 4.0
+    ref = (F.conv2d(x, wt, padding=k // 2) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)).clamp(0, 6)
+    if use_res:
+        ref = ref + res
+    assert (nchw(split) - ref).abs().max().item() <= TOL["f32"] * 4.0
+
+
 def test_conv1x1_channel_slices(ops):
     """Reading from and writing into channel slices of wider buffers (how torch.cat disappears)."""
     n, h, w = 2, 6, 9

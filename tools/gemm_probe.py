@@ -9,7 +9,7 @@ lib = L.load()
 dev = torch.device("cuda")
 
 
-def run(M_hw, n_img, cin, cout, taps, prec, tile, iters=20, act=1, scale=True):
+def run(M_hw, n_img, cin, cout, taps, prec, tile, iters=20, act=1, scale=True, stream_k=False):
     h, w = M_hw
     a = torch.rand((n_img * h * w, cin), device=dev) * 2 - 1
     wt = (torch.rand((cout, cin, 3 if taps == 9 else 1, 3 if taps == 9 else 1)) - 0.5) * 0.1
@@ -25,6 +25,9 @@ def run(M_hw, n_img, cin, cout, taps, prec, tile, iters=20, act=1, scale=True):
     d.out, d.ldc, d.o_img_stride = out.data_ptr(), cout, h * w
     d.n_img, d.H, d.W, d.Cin, d.Cout, d.taps = n_img, h, w, cin, cout, taps
     d.prec, d.act, d.epi, d.tile = L.PREC[prec], act, 0, tile
+    if stream_k:
+        ws = torch.zeros(int(lib.uavsal_streamk_workspace_bytes()), dtype=torch.uint8, device=dev)
+        d.sk_ws, d.sk_ws_bytes = ws.data_ptr(), ws.numel()
     plan = C.c_void_p(lib.uavsal_plan_create())
     lib.uavsal_plan_add_conv(plan, C.byref(d))
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
