@@ -998,8 +998,9 @@ int launch_variant(const ConvK& k0, int taps, hipStream_t stream) {
 static inline int streamk_grid(long long nblk, int kstages, int cus) {
     const int G = 2 * cus;
     // each range covers >= half a tile; short K loops lose more to publishing / collecting the 64 KB
-    // partial tiles than they win (K=256: 48 -> 68 us), long ones win 2-40 % (profiles/r1_streamk_probe.log)
-    if (nblk < G / 2 + 1 || nblk >= 3LL * cus * 3 || kstages < 48 || nblk % G == 0) return 0;
+    // partial tiles than they win (K=512: 80 -> 90 us, K=768 even; the 2700-tile K=256 expands 227 -> 259),
+    // long ones win 8-40 % (profiles/r1_streamk_probe.log)
+    if (nblk < G / 2 + 1 || nblk >= 3LL * cus * 3 || kstages < 64 || nblk % G == 0) return 0;
     const long long per_cu3 = (nblk + 3LL * cus - 1) / (3LL * cus);           // rounds at 3 workgroups per CU
     const double eff = (double)nblk / (double)(per_cu3 * 3 * cus);
     return eff < 0.93 ? G : 0;

@@ -115,8 +115,8 @@ def test_conv_wide_tile(ops, prec, case, tile):
 
 @pytest.mark.parametrize("case", [(8, 45, 80, 1536, 256, 1, True),     # 450 tiles, 96 K stages: the projections
                                   (8, 45, 80, 448, 256, 9, False),     # 450 tiles, 3x3 (conv_last)
-                                  (8, 45, 80, 768, 256, 1, True),      # 450 tiles, 48 K stages (the shortest taken)
-                                  (8, 45, 80, 800, 768, 1, False),     # 1350 tiles: ranges of 2.6 tiles
+                                  (8, 45, 80, 1024, 256, 1, True),     # 450 tiles, 64 K stages (the shortest taken)
+                                  (8, 45, 80, 1040, 768, 1, False),    # 1350 tiles: ranges of 2.6 tiles
                                   (5, 45, 80, 1024, 256, 1, False),    # 282 tiles: ranges of 0.55 tile (3 pieces)
                                   (8, 45, 80, 256, 256, 1, True)])     # short K: stays whole-tile
 def test_conv_stream_k(ops, case):
