@@ -892,11 +892,15 @@ __global__ __launch_bounds__(256, SK ? 2 : ((WM * WN >= 4) ? 3 : 4)) void conv_g
                             const float* src = part + ((size_t)(i * WN * 4 + n) * 256 + lane_idx) * 4;
                             asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(t[n]) : "v"(src) : "memory");
                         }
-                        static_assert(WN * 4 == 8, "the wait below names eight registers");
+                        static_assert(WN == 1 || WN == 2, "the waits below name 4 or 8 registers");
                         // the loads are invisible to the compiler's waitcnt pass: tie the results to the wait
-                        asm volatile("s_waitcnt vmcnt(0)"
-                                     : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]),
-                                       "+v"(t[6]), "+v"(t[7]) :: "memory");
+                        if constexpr (WN == 2)
+                            asm volatile("s_waitcnt vmcnt(0)"
+                                         : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]),
+                                           "+v"(t[6]), "+v"(t[WN * 4 - 1]) :: "memory");
+                        else
+                            asm volatile("s_waitcnt vmcnt(0)"
+                                         : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]) :: "memory");
 #pragma unroll
                         for (int n = 0; n < WN * 4; ++n)
 #pragma unroll
@@ -993,28 +997,41 @@ int launch_variant(const ConvK& k0, int taps, hipStream_t stream) {
     return uavsal_launch_status();
 }
 
-// stream-K is used for the 128 x 128 fp32 tile when whole-tile scheduling would leave part of the
-// chip idle in the last round; grid = 2 workgroups per CU (measured best for these shapes)
-static inline int streamk_grid(long long nblk, int kstages, int cus) {
-    const int G = 2 * cus;
-    // each range covers >= half a tile; short K loops lose more to publishing / collecting the 64 KB
-    // partial tiles than they win (K=512: 80 -> 90 us, K=768 even; the 2700-tile K=256 expands 227 -> 259),
-    // long ones win 8-40 % (profiles/r1_streamk_probe.log)
-    if (nblk < G / 2 + 1 || nblk >= 3LL * cus * 3 || kstages < 64 || nblk % G == 0) return 0;
+// stream-K is used when whole-tile scheduling would leave part of the chip idle in the last round;
+// grid = 2 workgroups per CU (measured best for these shapes), never more than are resident at once
+// (a workgroup may wait for a piece that a higher-numbered one computes first)
+static inline int streamk_grid(long long nblk, int kstages, int cus, int cap) {
+    int G = 2 * cus;
+    if (G > cap) G = cap;
+    // short K loops lose more to publishing / collecting the partial tiles than they win (K=512: 80 -> 90 us,
+    // K=768 even; the 2700-tile K=256 expands 227 -> 259), long ones win 8-40 % (profiles/r1_streamk_probe.log)
+    if (nblk < G / 4 + 1 || nblk >= 3LL * cus * 3 || kstages < 64 || nblk % G == 0) return 0;
     const long long per_cu3 = (nblk + 3LL * cus - 1) / (3LL * cus);           // rounds at 3 workgroups per CU
     const double eff = (double)nblk / (double)(per_cu3 * 3 * cus);
     return eff < 0.93 ? G : 0;
 }
 
-template <int TAPS>
-int launch_f32_streamk(const ConvK& k0, int G, hipStream_t stream) {
-    constexpr int SMEM = 3 * (128 + 128) * 64;
-    ConvK k = k0;
-    k.tiles_n = (k.Cout + 127) / 128;
-    k.nblk = ((k.M + 127) / 128) * k.tiles_n;
-    hipLaunchKernelGGL((conv_gemm_f32_dma_kernel<2, 2, 2, 2, TAPS, 3, 1, true>), dim3(G), dim3(256), SMEM, stream, k);
-    return uavsal_launch_status();
-}
+// (block tile, ring) configurations that have a stream-K instance
+template <int WAVES_M, int WAVES_N, int WM, int WN, int S, int NKP>
+struct SkCfg {
+    static constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32, SMEM = S * NKP * (BM + BN) * 64, STAGE_K = 16 * NKP;
+    template <int TAPS>
+    static int cap() {
+        static const int c = resident_grid(conv_gemm_f32_dma_kernel<WAVES_M, WAVES_N, WM, WN, TAPS, S, NKP, true>, SMEM);
+        return c;
+    }
+    template <int TAPS>
+    static int launch(const ConvK& k0, int G, hipStream_t stream) {
+        ConvK k = k0;
+        k.tiles_n = (k.Cout + BN - 1) / BN;
+        k.nblk = ((k.M + BM - 1) / BM) * k.tiles_n;
+        hipLaunchKernelGGL((conv_gemm_f32_dma_kernel<WAVES_M, WAVES_N, WM, WN, TAPS, S, NKP, true>), dim3(G), dim3(256),
+                           SMEM, stream, k);
+        return uavsal_launch_status();
+    }
+};
+typedef SkCfg<2, 2, 2, 2, 3, 1> SkBig;      // 128 x 128
+typedef SkCfg<2, 2, 1, 1, 3, 2> SkSmall;    // 64 x 64, 32-deep stages: 48 KB of LDS, so three fit a CU
 
 template <int WAVES_M, int WAVES_N, int WM, int WN, int S, int NKP>
 int launch_f32_dma(const ConvK& k0, int taps, hipStream_t stream) {
@@ -1096,7 +1113,7 @@ extern "C" long long uavsal_streamk_workspace_bytes(void) {
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
     const long long G = 2LL * n;
-    return G * 128 * 128 * 4 + (G + 1) * 4;
+    return 65536 + G * 128 * 128 * 4;
 }
 
 extern "C" int uavsal_conv_tile(const uavsal_conv_desc* d) {
@@ -1168,20 +1185,27 @@ extern "C" int uavsal_conv_gemm(const uavsal_conv_desc* d, uavsal_stream_t strea
     }
     if (d->epi == UAVSAL_EPI_LSTM) tile = 4;     // the LSTM update lives in the 64x64 tile's vector epilogue
     hipStream_t s = (hipStream_t)stream;
-    if (d->prec == UAVSAL_PREC_F32 && tile == 1 && !k.dw_w && d->sk_ws && uavsal_aligned16(d->sk_ws)) {
+    if (d->prec == UAVSAL_PREC_F32 && (tile == 1 || tile == 4) && !k.dw_w && d->epi != UAVSAL_EPI_LSTM &&
+        d->sk_ws && uavsal_aligned16(d->sk_ws)) {
         static const int cus = [] {
             int dev = 0, n = 0;
             if (hipGetDevice(&dev) != hipSuccess ||
                 hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
             return n;
         }();
-        const long long nblk = ((M + 127) / 128) * ((d->Cout + 127) / 128);
-        const int G = streamk_grid(nblk, k.ktiles, cus);
-        const long long need = (long long)G * 128 * 128 * 4 + (long long)(G + 1) * 4;
-        if (G > 0 && d->sk_ws_bytes >= need) {
-            k.sk_part = (float*)d->sk_ws;
-            k.sk_flag = (int*)((char*)d->sk_ws + (long long)G * 128 * 128 * 4);
-            return d->taps == 1 ? launch_f32_streamk<1>(k, G, s) : launch_f32_streamk<9>(k, G, s);
+        const int bt = tile == 1 ? 128 : 64;
+        const long long nblk = ((M + bt - 1) / bt) * ((d->Cout + bt - 1) / bt);
+        const int cap = tile == 1 ? (d->taps == 1 ? SkBig::cap<1>() : SkBig::cap<9>())
+                                  : (d->taps == 1 ? SkSmall::cap<1>() : SkSmall::cap<9>());
+        const int kstages = tile == 1 ? k.ktiles : (k.ktiles + 1) / 2;
+        const int G = streamk_grid(nblk, kstages, cus, cap);
+        // workspace: 64 KB of flags (one per workgroup + a "wait gave up" word), then the partial tiles
+        const long long need = 65536 + (long long)G * bt * bt * 4;
+        if (G > 0 && G < 16000 && d->sk_ws_bytes >= need) {
+            k.sk_flag = (int*)d->sk_ws;
+            k.sk_part = (float*)((char*)d->sk_ws + 65536);
+            if (tile == 1) return d->taps == 1 ? SkBig::launch<1>(k, G, s) : SkBig::launch<9>(k, G, s);
+            return d->taps == 1 ? SkSmall::launch<1>(k, G, s) : SkSmall::launch<9>(k, G, s);
         }
     }
     switch (d->prec) {

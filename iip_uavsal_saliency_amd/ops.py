@@ -77,13 +77,12 @@ def conv_gemm(x, weight, scale=None, bias=None, act=L.ACT_NONE, res=None, out=No
     if stream_k:
         # the kernels leave the workspace zeroed; a set word means a published piece was never consumed,
         # or the bounded wait for one gave up
-        g = (ws.numel() - 4) // (128 * 128 * 4 + 4)          # [g partial tiles][g flags + 1 timeout word]
-        if int(ws.view(torch.int32)[-(g + 1):].abs().sum().item()) != 0:
+        if int(ws[:65536].view(torch.int32).abs().sum().item()) != 0:      # the flag block (uavsal_hip.h)
             raise RuntimeError("stream-K workspace not clean after the launch")
     return out
 
 
-def twa_step(x_t, h_prev, pre_t, w_h, prec="f32", tile=0):
+def twa_step(x_t, h_prev, pre_t, w_h, prec="f32", tile=0, stream_k=False):
     """One ConvTWA step given pre_t = conv3x3(W[:, :C], x_t): returns h_t (NHWC)."""
     lib = L.load()
     ap, lda, n, h, w, c = _nhwc_view(h_prev)
@@ -99,8 +98,13 @@ def twa_step(x_t, h_prev, pre_t, w_h, prec="f32", tile=0):
     d.aux, d.ldx, d.x_img_stride = pp, ldx, h * w
     d.n_img, d.H, d.W, d.Cin, d.Cout, d.taps = n, h, w, c, c, 9
     d.prec, d.act, d.epi, d.tile = L.PREC[prec], L.ACT_NONE, L.EPI_TWA, tile
+    if stream_k:
+        ws = torch.zeros(int(lib.uavsal_streamk_workspace_bytes()), dtype=torch.uint8, device=x_t.device)
+        d.sk_ws, d.sk_ws_bytes = ws.data_ptr(), ws.numel()
     L.check(lib.uavsal_conv_gemm(C.byref(d), _stream(x_t)), "uavsal_conv_gemm(TWA)")
     torch.cuda.current_stream(x_t.device).synchronize()
+    if stream_k and int(ws[:65536].view(torch.int32).abs().sum().item()) != 0:
+        raise RuntimeError("stream-K workspace not clean after the launch")
     return out
 
 

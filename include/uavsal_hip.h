@@ -122,7 +122,7 @@ typedef struct uavsal_conv_desc {
      * dw_w9c is tap-major [9][Cin] as in uavsal_dw_desc; a_img_stride counts input pixels. */
     const float* dw_w9c; const float* dw_scale; const float* dw_bias;
     int32_t dw_stride, dw_Hin, dw_Win;
-    /* Optional stream-K workspace (fp32, 128x128 tile): `uavsal_streamk_workspace_bytes()` bytes of device
+    /* Optional stream-K workspace (fp32, 128x128 and 64x64 tiles; 64 KB of flags, then partial tiles): `uavsal_streamk_workspace_bytes()` bytes of device
      * memory, 16-byte aligned, ZERO-filled once by the caller and then owned by launches that are ordered
      * on one stream (the kernels leave it zeroed).  With it, launches whose tile count would idle part of
      * the chip in the last round split the K loop of some tiles across workgroups; the summation order

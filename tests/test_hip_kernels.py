@@ -182,6 +182,22 @@ def test_twa_step(ops, prec):
     assert err <= TOL[prec] * 4.0, (prec, err)
 
 
+def test_twa_step_stream_k(ops):
+    """The ConvTWA step at the headline size (1 x 45 x 80: 228 tiles of 64 x 64) with the stream-K workspace:
+    every tile is cut into 2-3 pieces, collected by the owner of its first K stage."""
+    n, c, h, w = 1, 256, 45, 80
+    x = rnd((n, c, h, w), 44, 2.0)
+    hp = rnd((n, c, h, w), 45, 2.0)
+    wt = rnd((c, 2 * c, 3, 3), 46, 1.0 / np.sqrt(9 * 2 * c))
+    gate = torch.sigmoid(F.conv2d(torch.cat([x, hp], 1), wt, padding=1))
+    ref = gate * x + (1 - gate) * hp
+    pre = ops.conv_gemm(nhwc(x), wt[:, :c].contiguous(), None, None, prec="f32")
+    whole = ops.twa_step(nhwc(x), nhwc(hp), pre, wt[:, c:].contiguous(), prec="f32")
+    split = ops.twa_step(nhwc(x), nhwc(hp), pre, wt[:, c:].contiguous(), prec="f32", stream_k=True)
+    assert (split - whole).abs().max().item() <= TOL["f32"] * 4.0
+    assert (nchw(split) - ref).abs().max().item() <= TOL["f32"] * 4.0
+
+
 @pytest.mark.parametrize("prec", ["f32", "f16x3"])
 def test_convlstm_step_vs_reference_golden(ops, prec, golden_dir):
     """ConvLSTMCell.forward: the golden was produced by the reference's own model_convlstm.py."""
