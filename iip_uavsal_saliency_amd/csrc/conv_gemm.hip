@@ -1000,9 +1000,18 @@ int launch_variant(const ConvK& k0, int taps, hipStream_t stream) {
 // stream-K is used when whole-tile scheduling would leave part of the chip idle in the last round;
 // grid = 2 workgroups per CU (measured best for these shapes), never more than are resident at once
 // (a workgroup may wait for a piece that a higher-numbered one computes first)
-static inline int streamk_grid(long long nblk, int kstages, int cus, int cap) {
+static inline int streamk_grid(long long nblk, int kstages, int cus, int cap, bool small_tile) {
     int G = 2 * cus;
     if (G > cap) G = cap;
+    if (small_tile) {
+        // 64 x 64 tiles (16 KB partials): few tiles with a long serial K loop (the 12x20 / 23x40 maps of
+        // the backbone tail) are latency-bound, so K is spread over as many workgroups as get >= 12 stages
+        const long long by_len = nblk * kstages / 12;
+        if (by_len < G) G = (int)by_len;
+        if (G < 2 || nblk < G / 6 + 1 || nblk >= 3LL * cus * 3 || kstages < 24 || nblk % G == 0) return 0;
+        const long long per_cu3 = (nblk + 3LL * cus - 1) / (3LL * cus);
+        return (double)nblk / (double)(per_cu3 * 3 * cus) < 0.93 ? G : 0;
+    }
     // short K loops lose more to publishing / collecting the partial tiles than they win (K=512: 80 -> 90 us,
     // K=768 even; the 2700-tile K=256 expands 227 -> 259), long ones win 8-40 % (profiles/r1_streamk_probe.log)
     if (nblk < G / 4 + 1 || nblk >= 3LL * cus * 3 || kstages < 64 || nblk % G == 0) return 0;
@@ -1198,7 +1207,7 @@ extern "C" int uavsal_conv_gemm(const uavsal_conv_desc* d, uavsal_stream_t strea
         const int cap = tile == 1 ? (d->taps == 1 ? SkBig::cap<1>() : SkBig::cap<9>())
                                   : (d->taps == 1 ? SkSmall::cap<1>() : SkSmall::cap<9>());
         const int kstages = tile == 1 ? k.ktiles : (k.ktiles + 1) / 2;
-        const int G = streamk_grid(nblk, kstages, cus, cap);
+        const int G = streamk_grid(nblk, kstages, cus, cap, tile == 4);
         // workspace: 64 KB of flags (one per workgroup + a "wait gave up" word), then the partial tiles
         const long long need = 65536 + (long long)G * bt * bt * 4;
         if (G > 0 && G < 16000 && d->sk_ws_bytes >= need) {
