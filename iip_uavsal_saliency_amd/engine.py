@@ -600,6 +600,14 @@ class Engine:
                 taps["logits"] = self.logits.clone().view(self.N, 1, self.h, self.w)
         return out, st
 
+    def streamk_clean(self) -> bool:
+        """True when the stream-K workspace's flag block is all zero, as every launch must leave it (a set
+        word is a published piece that nobody collected, or a bounded wait that gave up).  Synchronises."""
+        if self._sk_ws is None:
+            return True
+        torch.cuda.synchronize(self.device)
+        return int(self._sk_ws[:65536].view(torch.int32).abs().sum().item()) == 0
+
     def tap(self, name) -> torch.Tensor:
         """NCHW copy of a named NHWC buffer (debug / parity tests)."""
         v = self.named[name]

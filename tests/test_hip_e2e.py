@@ -90,6 +90,8 @@ def test_forward_vs_reference_golden(hip_model, golden_dir, name, prec):
         assert err <= MAP_TOL[prec], (name, prec, c, err)
         serr = np.abs(st.contiguous().view(-1).numpy()[::int(g["state_stride"])] - g["state" + sfx]).max()
         assert serr <= STATE_TOL[prec], (name, prec, c, serr)
+    # every stream-K launch must leave its workspace zeroed (nothing published and never collected)
+    assert all(e.streamk_clean() for e in hip_model._engines.values())
 
 
 def test_bf16_single_pass_error_is_reported(hip_model, oracle):
