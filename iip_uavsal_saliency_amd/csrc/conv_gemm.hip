@@ -1041,6 +1041,7 @@ struct SkCfg {
 };
 typedef SkCfg<2, 2, 2, 2, 3, 1> SkBig;      // 128 x 128
 typedef SkCfg<2, 2, 1, 1, 3, 2> SkSmall;    // 64 x 64, 32-deep stages: 48 KB of LDS, so three fit a CU
+typedef SkCfg<4, 1, 1, 1, 4, 1> SkThin;     // 128 x 32 (Cout <= 32: the 1536 -> 1 decoder projection streams HBM)
 
 template <int WAVES_M, int WAVES_N, int WM, int WN, int S, int NKP>
 int launch_f32_dma(const ConvK& k0, int taps, hipStream_t stream) {
@@ -1194,7 +1195,7 @@ extern "C" int uavsal_conv_gemm(const uavsal_conv_desc* d, uavsal_stream_t strea
     }
     if (d->epi == UAVSAL_EPI_LSTM) tile = 4;     // the LSTM update lives in the 64x64 tile's vector epilogue
     hipStream_t s = (hipStream_t)stream;
-    if (d->prec == UAVSAL_PREC_F32 && (tile == 1 || tile == 4) && !k.dw_w && d->epi != UAVSAL_EPI_LSTM &&
+    if (d->prec == UAVSAL_PREC_F32 && (tile == 1 || tile == 3 || tile == 4) && !k.dw_w && d->epi != UAVSAL_EPI_LSTM &&
         d->sk_ws && uavsal_aligned16(d->sk_ws)) {
         static const int cus = [] {
             int dev = 0, n = 0;
@@ -1202,19 +1203,22 @@ extern "C" int uavsal_conv_gemm(const uavsal_conv_desc* d, uavsal_stream_t strea
                 hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
             return n;
         }();
-        const int bt = tile == 1 ? 128 : 64;
-        const long long nblk = ((M + bt - 1) / bt) * ((d->Cout + bt - 1) / bt);
-        const int cap = tile == 1 ? (d->taps == 1 ? SkBig::cap<1>() : SkBig::cap<9>())
-                                  : (d->taps == 1 ? SkSmall::cap<1>() : SkSmall::cap<9>());
-        const int kstages = tile == 1 ? k.ktiles : (k.ktiles + 1) / 2;
-        const int G = streamk_grid(nblk, kstages, cus, cap, tile == 4);
+        const int bm = tile == 4 ? 64 : 128, bn = tile == 1 ? 128 : (tile == 3 ? 32 : 64);
+        const long long nblk = ((M + bm - 1) / bm) * ((d->Cout + bn - 1) / bn);
+        const bool t1 = d->taps == 1;
+        const int cap = tile == 1 ? (t1 ? SkBig::cap<1>() : SkBig::cap<9>())
+                      : tile == 3 ? (t1 ? SkThin::cap<1>() : SkThin::cap<9>())
+                                  : (t1 ? SkSmall::cap<1>() : SkSmall::cap<9>());
+        const int kstages = tile == 4 ? (k.ktiles + 1) / 2 : k.ktiles;
+        const int G = streamk_grid(nblk, kstages, cus, cap, tile != 1);
         // workspace: 64 KB of flags (one per workgroup + a "wait gave up" word), then the partial tiles
-        const long long need = 65536 + (long long)G * bt * bt * 4;
+        const long long need = 65536 + (long long)G * bm * bn * 4;
         if (G > 0 && G < 16000 && d->sk_ws_bytes >= need) {
             k.sk_flag = (int*)d->sk_ws;
             k.sk_part = (float*)((char*)d->sk_ws + 65536);
-            if (tile == 1) return d->taps == 1 ? SkBig::launch<1>(k, G, s) : SkBig::launch<9>(k, G, s);
-            return d->taps == 1 ? SkSmall::launch<1>(k, G, s) : SkSmall::launch<9>(k, G, s);
+            if (tile == 1) return t1 ? SkBig::launch<1>(k, G, s) : SkBig::launch<9>(k, G, s);
+            if (tile == 3) return t1 ? SkThin::launch<1>(k, G, s) : SkThin::launch<9>(k, G, s);
+            return t1 ? SkSmall::launch<1>(k, G, s) : SkSmall::launch<9>(k, G, s);
         }
     }
     switch (d->prec) {

@@ -69,7 +69,7 @@ class Engine:
         self.in_dtype = in_dtype
         self.use_graph = use_graph
         self.stream_k = bool(stream_k)
-        self._sk_ws = None
+        self._sk_ws = {}
         # fused depthwise->projection GEMM (uavsal_conv_desc.dw_*): D never reaches HBM.
         # Measured (profiles/README.md): as written -- nine dependent global loads per staged value, no
         # LDS-staged halo tile -- the fused loader is latency-bound and ~1.5x SLOWER end to end, so it is
@@ -242,12 +242,13 @@ class Engine:
         d.prec, d.act, d.epi, d.tile = self.prec, act, epi, 0
         if out2 is not None:
             d.out2, d.ld2 = out2.ptr, out2.ld
-        if self.stream_k and self._lane == 0:
-            # one workspace: launches on lane 0 are ordered on one stream (uavsal_conv_desc.sk_ws)
-            if self._sk_ws is None:
-                self._sk_ws = torch.zeros(int(self.lib.uavsal_streamk_workspace_bytes()), dtype=torch.uint8,
-                                          device=self.device)
-            d.sk_ws, d.sk_ws_bytes = self._sk_ws.data_ptr(), self._sk_ws.numel()
+        if self.stream_k:
+            # one workspace per lane: launches on a lane are ordered on one stream (uavsal_conv_desc.sk_ws)
+            ws = self._sk_ws.get(self._lane)
+            if ws is None:
+                ws = self._sk_ws[self._lane] = torch.zeros(int(self.lib.uavsal_streamk_workspace_bytes()),
+                                                           dtype=torch.uint8, device=self.device)
+            d.sk_ws, d.sk_ws_bytes = ws.data_ptr(), ws.numel()
         self.ops_meta[-1]["tile"] = int(self.lib.uavsal_conv_tile(C.byref(d)))
         self._add(self.lib.uavsal_plan_add_conv, d, "plan_add_conv(%s)" % name)
 
@@ -603,10 +604,8 @@ class Engine:
     def streamk_clean(self) -> bool:
         """True when the stream-K workspace's flag block is all zero, as every launch must leave it (a set
         word is a published piece that nobody collected, or a bounded wait that gave up).  Synchronises."""
-        if self._sk_ws is None:
-            return True
         torch.cuda.synchronize(self.device)
-        return int(self._sk_ws[:65536].view(torch.int32).abs().sum().item()) == 0
+        return all(int(ws[:65536].view(torch.int32).abs().sum().item()) == 0 for ws in self._sk_ws.values())
 
     def tap(self, name) -> torch.Tensor:
         """NCHW copy of a named NHWC buffer (debug / parity tests)."""
