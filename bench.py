@@ -39,23 +39,25 @@ DTYPE_NAME = {"f32": "f32", "f16x3": "f32 (3x f16 split MFMA, f32 accumulate)",
 TILE_NAME = {1: "128x128", 2: "128x64", 3: "128x32", 4: "64x64"}
 PREC_ID = {"f32": 0, "bf16x3": 1, "bf16": 2, "f16x3": 3}
 # template arguments of the kernel instance each (precision, tile) launches, as rocprofv3 prints them
-F32_INST = {1: "2, 2, 2, 2, %d, 3, 1", 2: "4, 1, 1, 2, %d, 4, 1", 3: "4, 1, 1, 1, %d, 4, 1", 4: "2, 2, 1, 1, %d, 3, 4"}
+F32_INST = {1: "2, 2, 2, 2, %d, 3, 1, false", 2: "4, 1, 1, 2, %d, 4, 1, false", 3: "4, 1, 1, 1, %d, 4, 1, false",
+            4: "2, 2, 1, 1, %d, 3, 4, false"}
+F32_SK_INST = {1: "2, 2, 2, 2, %d, 3, 1, true", 3: "4, 1, 1, 1, %d, 4, 1, true", 4: "2, 2, 1, 1, %d, 3, 2, true"}   # stream-K
 H16_INST = {1: "%d, 2, 2, 2, 2, %d", 2: "%d, 4, 1, 1, 2, %d", 3: "%d, 4, 1, 1, 1, %d", 4: "%d, 2, 2, 1, 1, %d",
             5: "%d, 2, 4, 2, 2, %d", 6: "%d, 2, 4, 4, 2, %d"}
 
 
-def kernel_symbol(prec, tile, taps):
+def kernel_symbol(prec, tile, taps, streamk=0):
     if prec == "f32":
-        return "conv_gemm_f32_dma_kernel<%s>" % (F32_INST[tile] % taps)
+        return "conv_gemm_f32_dma_kernel<%s>" % ((F32_SK_INST if streamk else F32_INST)[tile] % taps)
     return "conv_gemm_kernel<%s>" % (H16_INST[tile] % (PREC_ID[prec], taps))
 
 
 def measured_traffic(symbol, C, T, H, W, prec):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950
-    note, + WRITE_SIZE; profiles/r1_hbm_traffic_f32_c1_v2.json, collected for configs[1] only)."""
+    note, + WRITE_SIZE; profiles/r1_hbm_traffic_f32_c1_v3.json, collected for configs[1] only)."""
     if (C, T, H, W, prec) != (1, 8, 360, 640, "f32"):
         return None
-    path = os.path.join(ROOT, "profiles", "r1_hbm_traffic_f32_c1_v2.json")
+    path = os.path.join(ROOT, "profiles", "r1_hbm_traffic_f32_c1_v3.json")
     if not os.path.exists(path):
         return None
     rec = json.load(open(path)).get(symbol)
@@ -97,7 +99,7 @@ def kernel_rooflines(eng, prec, iters=5):
     for i, m in enumerate(eng.ops_meta):
         ms = eng.time_ops(i, i + 1, iters)
         if m["kind"].startswith("conv"):
-            key = kernel_symbol(prec, m["tile"], 9 if m["kind"] == "conv3" else 1)
+            key = kernel_symbol(prec, m["tile"], 9 if m["kind"] == "conv3" else 1, m.get("streamk", 0))
             if m.get("fused_dw"):
                 key = "conv_gemm_kernel<%s, true>" % (H16_INST[m["tile"]] % (PREC_ID[prec], 1))
         elif m["kind"] == "dw":

@@ -85,6 +85,7 @@ SYMBOLS = [
     ("uavsal_conv_gemm", C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     ("uavsal_conv_tile", C.c_int, [C.POINTER(ConvDesc)]),
     ("uavsal_streamk_workspace_bytes", C.c_longlong, []),
+    ("uavsal_conv_streamk_grid", C.c_int, [C.POINTER(ConvDesc)]),
     ("uavsal_dw3x3", C.c_int, [C.POINTER(DwDesc), C.c_void_p]),
     ("uavsal_stem_conv", C.c_int, [C.POINTER(StemDesc), C.c_void_p]),
     ("uavsal_bilinear_ac", C.c_int, [C.POINTER(BilinearDesc), C.c_void_p]),

@@ -1093,6 +1093,30 @@ int launch_prec(const ConvK& k, int taps, int tile, hipStream_t stream) {
     }
 }
 
+// grid of the stream-K launch this descriptor would get with block tile `tile`, or 0 (whole tiles)
+int streamk_plan(const uavsal_conv_desc* d, int tile, int ktiles) {
+    if (d->prec != UAVSAL_PREC_F32 || !(tile == 1 || tile == 3 || tile == 4) || d->dw_w9c ||
+        d->epi == UAVSAL_EPI_LSTM || !d->sk_ws || !uavsal_aligned16(d->sk_ws))
+        return 0;
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
+    const long long M = (long long)d->H * d->W * d->n_img;
+    const int bm = tile == 4 ? 64 : 128, bn = tile == 1 ? 128 : (tile == 3 ? 32 : 64);
+    const long long nblk = ((M + bm - 1) / bm) * ((d->Cout + bn - 1) / bn);
+    const bool t1 = d->taps == 1;
+    const int cap = tile == 1 ? (t1 ? SkBig::cap<1>() : SkBig::cap<9>())
+                  : tile == 3 ? (t1 ? SkThin::cap<1>() : SkThin::cap<9>())
+                              : (t1 ? SkSmall::cap<1>() : SkSmall::cap<9>());
+    const int kstages = tile == 4 ? (ktiles + 1) / 2 : ktiles;
+    const int G = streamk_grid(nblk, kstages, cus, cap, tile != 1);
+    if (G <= 0 || G >= 16000 || d->sk_ws_bytes < 65536 + (long long)G * bm * bn * 4) return 0;
+    return G;
+}
+
 int pick_tile(long long M, int Cout, int prec) {
     // Largest tile that still hands every one of the 256 CUs at least one workgroup: measured on
     // the path's shapes (profiles/r1_gemm_probe.log) 128x128 beats 128x64 / 64x64 as soon as there
@@ -1124,6 +1148,13 @@ extern "C" long long uavsal_streamk_workspace_bytes(void) {
         hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
     const long long G = 2LL * n;
     return 65536 + G * 128 * 128 * 4;
+}
+
+extern "C" int uavsal_conv_streamk_grid(const uavsal_conv_desc* d) {
+    if (!d || d->n_img <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0) return 0;
+    const int tile = uavsal_conv_tile(d);
+    const int KT = d->prec == UAVSAL_PREC_F32 ? 16 : 32;
+    return tile > 0 ? streamk_plan(d, tile, (d->taps * d->Cin + KT - 1) / KT) : 0;
 }
 
 extern "C" int uavsal_conv_tile(const uavsal_conv_desc* d) {
@@ -1195,27 +1226,13 @@ extern "C" int uavsal_conv_gemm(const uavsal_conv_desc* d, uavsal_stream_t strea
     }
     if (d->epi == UAVSAL_EPI_LSTM) tile = 4;     // the LSTM update lives in the 64x64 tile's vector epilogue
     hipStream_t s = (hipStream_t)stream;
-    if (d->prec == UAVSAL_PREC_F32 && (tile == 1 || tile == 3 || tile == 4) && !k.dw_w && d->epi != UAVSAL_EPI_LSTM &&
-        d->sk_ws && uavsal_aligned16(d->sk_ws)) {
-        static const int cus = [] {
-            int dev = 0, n = 0;
-            if (hipGetDevice(&dev) != hipSuccess ||
-                hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-            return n;
-        }();
-        const int bm = tile == 4 ? 64 : 128, bn = tile == 1 ? 128 : (tile == 3 ? 32 : 64);
-        const long long nblk = ((M + bm - 1) / bm) * ((d->Cout + bn - 1) / bn);
-        const bool t1 = d->taps == 1;
-        const int cap = tile == 1 ? (t1 ? SkBig::cap<1>() : SkBig::cap<9>())
-                      : tile == 3 ? (t1 ? SkThin::cap<1>() : SkThin::cap<9>())
-                                  : (t1 ? SkSmall::cap<1>() : SkSmall::cap<9>());
-        const int kstages = tile == 4 ? (k.ktiles + 1) / 2 : k.ktiles;
-        const int G = streamk_grid(nblk, kstages, cus, cap, tile != 1);
-        // workspace: 64 KB of flags (one per workgroup + a "wait gave up" word), then the partial tiles
-        const long long need = 65536 + (long long)G * bm * bn * 4;
-        if (G > 0 && G < 16000 && d->sk_ws_bytes >= need) {
+    {
+        const int G = streamk_plan(d, tile, k.ktiles);
+        if (G > 0) {
+            // workspace: 64 KB of flags (one per workgroup + a "wait gave up" word), then the partial tiles
             k.sk_flag = (int*)d->sk_ws;
             k.sk_part = (float*)((char*)d->sk_ws + 65536);
+            const bool t1 = d->taps == 1;
             if (tile == 1) return t1 ? SkBig::launch<1>(k, G, s) : SkBig::launch<9>(k, G, s);
             if (tile == 3) return t1 ? SkThin::launch<1>(k, G, s) : SkThin::launch<9>(k, G, s);
             return t1 ? SkSmall::launch<1>(k, G, s) : SkSmall::launch<9>(k, G, s);

@@ -250,6 +250,7 @@ class Engine:
                                                            dtype=torch.uint8, device=self.device)
             d.sk_ws, d.sk_ws_bytes = ws.data_ptr(), ws.numel()
         self.ops_meta[-1]["tile"] = int(self.lib.uavsal_conv_tile(C.byref(d)))
+        self.ops_meta[-1]["streamk"] = int(self.lib.uavsal_conv_streamk_grid(C.byref(d)))
         self._add(self.lib.uavsal_plan_add_conv, d, "plan_add_conv(%s)" % name)
 
     def dw(self, name, a: V, conv, bn, out: V, stride, dilation):

@@ -135,6 +135,8 @@ int uavsal_conv_gemm(const uavsal_conv_desc* d, uavsal_stream_t stream);
 int uavsal_conv_tile(const uavsal_conv_desc* d);
 /* size of the optional stream-K workspace (see uavsal_conv_desc.sk_ws) */
 long long uavsal_streamk_workspace_bytes(void);
+/* workgroups of the stream-K launch `uavsal_conv_gemm` will use for this descriptor, 0 = whole tiles; no launch */
+int uavsal_conv_streamk_grid(const uavsal_conv_desc* d);
 
 /*
  * Depthwise 3x3 convolution + folded BatchNorm + ReLU6, NHWC, stride 1 or 2,
