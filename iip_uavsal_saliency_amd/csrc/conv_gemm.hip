@@ -1121,7 +1121,7 @@ int pick_tile(long long M, int Cout, int prec) {
     // Largest tile that still hands every one of the 256 CUs at least one workgroup: measured on
     // the path's shapes (profiles/r1_gemm_probe.log) 128x128 beats 128x64 / 64x64 as soon as there
     // are >= 256 tiles (K=1536,N=256: 92 vs 73 TFLOP/s; 3x3 448->256: 91 vs 67), because the
-    // per-tile L2 traffic per FLOP halves.  N tile never wider than the 32-padded channel count.
+    // per-tile L2 traffic per FLOP halves.
     const int npad = (Cout + 31) / 32 * 32;
     if (npad <= 32) return 3;
     if ((prec == UAVSAL_PREC_F16X3 || prec == UAVSAL_PREC_BF16X3) && Cout % 256 == 0) {
@@ -1130,14 +1130,22 @@ int pick_tile(long long M, int Cout, int prec) {
         if (((M + 255) / 256) * (Cout / 256) >= 512) return 6;
         if (((M + 127) / 128) * (Cout / 256) >= 192) return 5;
     }
+    // Among the tiles that give >= 256 blocks: least padded-N work, the narrower tiles charged 5 / 35 % for
+    // their lower efficiency (Cout = 144: 128x64 27.8 us vs 128x128 33.2; 576: 42.2 vs 46.5; 96: 42.2 with
+    // 128x128 vs 50.3, same padding; 24: 128x32 19.9 vs 31.1 -- profiles/r1_gemm_probe_v3.log).
     const int cand_bm[4] = {128, 128, 128, 64};
     const int cand_bn[4] = {128, 64, 32, 64};
+    const int penalty[4] = {100, 105, 135, 140};
+    int best = 0;
+    long long best_cost = 0;
     for (int t = 0; t < 4; ++t) {
-        if (cand_bn[t] > npad) continue;      // don't waste N
-        const long long blocks = ((M + cand_bm[t] - 1) / cand_bm[t]) * ((Cout + cand_bn[t] - 1) / cand_bn[t]);
-        if (blocks >= 256) return t + 1;
+        const long long tn = (Cout + cand_bn[t] - 1) / cand_bn[t];
+        const long long blocks = ((M + cand_bm[t] - 1) / cand_bm[t]) * tn;
+        if (blocks < 256) continue;
+        const long long cost = tn * cand_bn[t] * penalty[t];
+        if (!best || cost < best_cost) { best = t + 1; best_cost = cost; }
     }
-    return 4;
+    return best ? best : 4;
 }
 
 }  // namespace
