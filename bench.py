@@ -103,7 +103,12 @@ def kernel_rooflines(eng, prec, iters=5):
             if m.get("fused_dw"):
                 key = "conv_gemm_kernel<%s, true>" % (H16_INST[m["tile"]] % (PREC_ID[prec], 1))
         elif m["kind"] == "dw":
-            key = "dw3x3_dilated_kernel" if m.get("dil", 1) != 1 else ("dw3x3_kernel<1, 4, 4>" if m.get("stride", 1) == 1 else "dw3x3_kernel<2, 2, 2>")
+            if m.get("dil", 1) != 1:
+                key = "dw3x3_dilated_kernel"
+            elif m.get("stride", 1) != 1:
+                key = "dw3x3_kernel<2, 2, 2>"
+            else:      # small maps take 2x2 patches (dw_conv.hip: fewer than 512 workgroups of 4x4 patches)
+                key = "dw3x3_kernel<1, 2, 2>" if (m.get("patches44", 1 << 30) + 255) // 256 < 512 else "dw3x3_kernel<1, 4, 4>"
         else:
             key = m["kind"]
         if os.environ.get("UAVSAL_BENCH_OPS"):

@@ -257,7 +257,8 @@ class Engine:
         c = a.c
         ho, wo = (a.h - 1) // stride + 1, (a.w - 1) // stride + 1
         byts = 4.0 * a.n * c * (a.h * a.w + ho * wo) + 4.0 * 9 * c + 4.0 * 2 * c
-        self._meta(kind="dw", name=name, flops=2.0 * 9 * a.n * ho * wo * c, bytes=byts, stride=stride, dil=dilation)
+        self._meta(kind="dw", name=name, flops=2.0 * 9 * a.n * ho * wo * c, bytes=byts, stride=stride, dil=dilation,
+                   patches44=a.n * ((ho + 3) // 4) * ((wo + 3) // 4) * (c // 4))
         if self._dry:
             return
         key = ("dw", id(conv))
