@@ -19,45 +19,66 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemK p) {
     for (int i = threadIdx.x; i < 27 * 32; i += 256) wsh[i] = p.w[i];
     if (threadIdx.x < 32) { ssh[threadIdx.x] = p.scale[threadIdx.x]; bsh[threadIdx.x] = p.bias[threadIdx.x]; }
     __syncthreads();
-    const long long item = (long long)blockIdx.x * 256 + threadIdx.x;   // (pixel, group of 8 channels)
+    // thread = (4 consecutive output pixels along x, group of 8 channels): a tap's 8 weights are read from
+    // LDS once for 4 pixels (one pixel per thread made this kernel LDS-read-bound: 60 us for 81 MB)
+    const long long item = (long long)blockIdx.x * 256 + threadIdx.x;
     if (item >= p.total) return;
     const int g = (int)(item & 3);
-    long long pix = item >> 2;
-    const int ox = (int)(pix % p.Wo); pix /= p.Wo;
-    const int oy = (int)(pix % p.Ho);
-    const int n = (int)(pix / p.Ho);
-    float acc[8];
+    long long t = item >> 2;
+    const int Wq = (p.Wo + 3) >> 2;
+    const int oxq = (int)(t % Wq); t /= Wq;
+    const int oy = (int)(t % p.Ho);
+    const int n = (int)(t / p.Ho);
+    const int ox0 = oxq * 4;
+    float acc[4][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[q][j] = 0.f;
     const size_t plane = (size_t)p.H * p.W;
 #pragma unroll
     for (int ci = 0; ci < 3; ++ci) {
+        const float mu = p.in_u8 ? p.mean[ci] : 0.f, sd = p.in_u8 ? p.stdv[ci] : 1.f;
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             const int iy = oy * 2 - 1 + ky;
+            const bool yok = iy >= 0 && iy < p.H;
+            const size_t rowi = ((size_t)n * 3 + ci) * plane + (size_t)(yok ? iy : 0) * p.W;
+            float v[9];                                  // input columns 2*ox0-1 .. 2*ox0+7
+#pragma unroll
+            for (int c = 0; c < 9; ++c) {
+                const int ix = ox0 * 2 - 1 + c;
+                float x = 0.f;
+                if (yok && ix >= 0 && ix < p.W) {
+                    if (p.in_u8) x = ((float)p.in_u8[rowi + ix] / 255.0f - mu) / sd;
+                    else x = p.in[rowi + ix];
+                }
+                v[c] = x;
+            }
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
-                const int ix = ox * 2 - 1 + kx;
-                float v = 0.f;
-                if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
-                    const size_t idx = ((size_t)n * 3 + ci) * plane + (size_t)iy * p.W + ix;
-                    if (p.in_u8) v = ((float)p.in_u8[idx] / 255.0f - p.mean[ci]) / p.stdv[ci];
-                    else v = p.in[idx];
-                }
                 const float* wr = wsh + (ci * 9 + ky * 3 + kx) * 32 + g * 8;
+                float w8[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] = fmaf(v, wr[j], acc[j]);
+                for (int j = 0; j < 8; ++j) w8[j] = wr[j];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[q][j] = fmaf(v[2 * q + kx], w8[j], acc[q][j]);
             }
         }
     }
-    float* o = p.out + (((size_t)n * p.Ho + oy) * p.Wo + ox) * p.ldo + g * 8;
-    f32x4 r0, r1;
-    float r[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) r[j] = fminf(fmaxf(acc[j] * ssh[g * 8 + j] + bsh[g * 8 + j], 0.f), 6.f);
-    r0 = (f32x4){r[0], r[1], r[2], r[3]}; r1 = (f32x4){r[4], r[5], r[6], r[7]};
-    *reinterpret_cast<f32x4*>(o) = r0;
-    *reinterpret_cast<f32x4*>(o + 4) = r1;
+    for (int q = 0; q < 4; ++q) {
+        const int ox = ox0 + q;
+        if (ox >= p.Wo) break;
+        float* o = p.out + (((size_t)n * p.Ho + oy) * p.Wo + ox) * p.ldo + g * 8;
+        float r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = fminf(fmaxf(acc[q][j] * ssh[g * 8 + j] + bsh[g * 8 + j], 0.f), 6.f);
+        *reinterpret_cast<f32x4*>(o) = (f32x4){r[0], r[1], r[2], r[3]};
+        *reinterpret_cast<f32x4*>(o + 4) = (f32x4){r[4], r[5], r[6], r[7]};
+    }
 }
 
 // ---------------------------------------------------------------- bilinear, align_corners=True
@@ -192,7 +213,7 @@ extern "C" int uavsal_stem_conv(const uavsal_stem_desc* d, uavsal_stream_t strea
     k.in = d->in; k.in_u8 = d->in_u8; k.w = d->w; k.scale = d->scale; k.bias = d->bias; k.out = d->out;
     k.ldo = d->ldo; k.H = d->H; k.W = d->W; k.Ho = (d->H - 1) / 2 + 1; k.Wo = (d->W - 1) / 2 + 1;
     for (int i = 0; i < 3; ++i) { k.mean[i] = d->mean[i]; k.stdv[i] = d->stdv[i]; }
-    k.total = (long long)d->n_img * k.Ho * k.Wo * 4;
+    k.total = (long long)d->n_img * k.Ho * ((k.Wo + 3) / 4) * 4;      // (4 pixels along x, 8-channel group) items
     int nblk; int e = grid_for(k.total, &nblk); if (e) return e;
     hipLaunchKernelGGL(stem_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, k);
     return uavsal_launch_status();
