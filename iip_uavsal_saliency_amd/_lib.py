@@ -18,7 +18,9 @@ EPI_AFFINE, EPI_TWA, EPI_LSTM = 0, 1, 2
 _ERR = {-1: "UAVSAL_EINVAL (null pointer / non-positive size)",
         -2: "UAVSAL_EALIGN (channel count / ld / pointer not 16-byte aligned)",
         -3: "UAVSAL_ESHAPE (shape not supported by the kernel)",
-        -4: "UAVSAL_ESTATE (plan used in the wrong state)"}
+        -4: "UAVSAL_ESTATE (plan used in the wrong state)",
+        -5: "UAVSAL_EDEVICE (a kernel reported a device-side error; the run's outputs are invalid)"}
+ERR_STREAMK = 1
 
 _f = C.c_void_p   # device pointers travel as integers
 
@@ -35,7 +37,8 @@ class ConvDesc(C.Structure):
                 ("out2", _f), ("ld2", C.c_int32),
                 ("dw_w9c", _f), ("dw_scale", _f), ("dw_bias", _f),
                 ("dw_stride", C.c_int32), ("dw_Hin", C.c_int32), ("dw_Win", C.c_int32),
-                ("sk_ws", _f), ("sk_ws_bytes", C.c_int64)]
+                ("sk_ws", _f), ("sk_ws_bytes", C.c_int64),
+                ("err", _f), ("sk_spin_limit", C.c_int32), ("sk_debug_drop", C.c_int32)]
 
 
 class DwDesc(C.Structure):
@@ -78,7 +81,16 @@ class PostDesc(C.Structure):
                 ("w", C.c_int32), ("H", C.c_int32), ("W", C.c_int32)]
 
 
-DESC_TYPES = [ConvDesc, DwDesc, StemDesc, BilinearDesc, TdiffDesc, TsumDesc, LayoutDesc, PostDesc]
+class GuardDesc(C.Structure):
+    _fields_ = [("err", _f), ("host_err", _f), ("buf", _f * 3), ("n", C.c_int64 * 3)]
+
+
+class CopyDesc(C.Structure):
+    _fields_ = [("inp", _f), ("out", _f), ("in_pitch", C.c_int64), ("out_pitch", C.c_int64),
+                ("row_floats", C.c_int64), ("rows", C.c_int32)]
+
+
+DESC_TYPES = [ConvDesc, DwDesc, StemDesc, BilinearDesc, TdiffDesc, TsumDesc, LayoutDesc, PostDesc, GuardDesc, CopyDesc]
 
 # every symbol include/uavsal_hip.h declares: (name, restype, argtypes)
 SYMBOLS = [
@@ -93,6 +105,9 @@ SYMBOLS = [
     ("uavsal_tsum", C.c_int, [C.POINTER(TsumDesc), C.c_void_p]),
     ("uavsal_layout", C.c_int, [C.POINTER(LayoutDesc), C.c_void_p]),
     ("uavsal_postprocess", C.c_int, [C.POINTER(PostDesc), C.c_void_p]),
+    ("uavsal_guard", C.c_int, [C.POINTER(GuardDesc), C.c_void_p]),
+    ("uavsal_copy_rows", C.c_int, [C.POINTER(CopyDesc), C.c_void_p]),
+    ("uavsal_plan_add_copy", C.c_int, [C.c_void_p, C.POINTER(CopyDesc)]),
     ("uavsal_plan_create", C.c_void_p, []),
     ("uavsal_plan_destroy", None, [C.c_void_p]),
     ("uavsal_plan_add_conv", C.c_int, [C.c_void_p, C.POINTER(ConvDesc)]),
@@ -102,6 +117,9 @@ SYMBOLS = [
     ("uavsal_plan_add_tdiff", C.c_int, [C.c_void_p, C.POINTER(TdiffDesc)]),
     ("uavsal_plan_add_tsum", C.c_int, [C.c_void_p, C.POINTER(TsumDesc)]),
     ("uavsal_plan_add_layout", C.c_int, [C.c_void_p, C.POINTER(LayoutDesc)]),
+    ("uavsal_plan_error_word", C.c_void_p, [C.c_void_p]),
+    ("uavsal_plan_add_guard", C.c_int, [C.c_void_p, _f, C.c_int64, _f, C.c_int64, _f, C.c_int64]),
+    ("uavsal_plan_status", C.c_int, [C.c_void_p, C.c_int]),
     ("uavsal_plan_set_lane", C.c_int, [C.c_void_p, C.c_int]),
     ("uavsal_plan_add_fork", C.c_int, [C.c_void_p, C.c_int]),
     ("uavsal_plan_add_join", C.c_int, [C.c_void_p, C.c_int]),
@@ -133,7 +151,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.uavsal_abi_version() != 7:
+    if lib.uavsal_abi_version() != 8:
         raise RuntimeError("libuavsal_hip.so ABI version mismatch")
     for i, t in enumerate(DESC_TYPES):
         if lib.uavsal_sizeof_desc(i) != C.sizeof(t):
@@ -146,6 +164,8 @@ def load():
 def check(code: int, what: str = "uavsal call"):
     if code == 0:
         return
+    if code == -5:
+        raise RuntimeError("%s: %s" % (what, _ERR[-5]))
     if code < 0:
         raise RuntimeError("%s rejected its arguments: %s" % (what, _ERR.get(code, str(code))))
     raise RuntimeError("%s failed with hipError_t %d" % (what, code))

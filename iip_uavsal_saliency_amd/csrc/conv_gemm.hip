@@ -50,6 +50,8 @@ struct ConvK {
     int tiles_n, nblk, contig;
     float* sk_part;      // stream-K: one BM x BN fp32 partial per workgroup ...
     int* sk_flag;        // ... and its "published" flag (0 at launch, reset by the consumer)
+    int* err;            // device error word (UAVSAL_ERR_*)
+    int sk_spin, sk_drop;
 };
 
 __device__ __forceinline__ long long row_off(int m, int HW, long long img_stride, int contig) {
@@ -225,6 +227,9 @@ __device__ __attribute__((aligned(16))) float g_zero16[4];
 
 #ifndef UAVSAL_SK_PREFETCH
 #define UAVSAL_SK_PREFETCH 1
+#endif
+#ifndef UAVSAL_SK_ACQUIRE
+#define UAVSAL_SK_ACQUIRE 1
 #endif
 #ifndef UAVSAL_GEMM_PREFETCH
 #define UAVSAL_GEMM_PREFETCH 2
@@ -796,6 +801,7 @@ __global__ __launch_bounds__(256, SK ? 2 : ((WM * WN >= 4) ? 3 : 4)) void conv_g
 
     const int nst = (kpanels + NKP - 1) / NKP;   // stages (groups of NKP panels) along K
     if constexpr (SK) {
+        __shared__ int sk_piece_ok;
         // ---- this XCD's tiles and this workgroup's range of their K stages -------------------
         const int G = gridDim.x, q = G / UAVSAL_NUM_XCD, r = G % UAVSAL_NUM_XCD;
         const int xcd = blockIdx.x % UAVSAL_NUM_XCD, slot = blockIdx.x / UAVSAL_NUM_XCD;
@@ -870,20 +876,35 @@ __global__ __launch_bounds__(256, SK ? 2 : ((WM * WN >= 4) ? 3 : 4)) void conv_g
                         }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
-                if (tid == 0) __hip_atomic_store(p.sk_flag + vb0 + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // (sk_drop: test hook -- this workgroup "loses" its piece, tests/test_hip_kernels.py)
+                if (tid == 0 && p.sk_drop != vb0 + slot + 1 && p.sk_drop >= 0)
+                    __hip_atomic_store(p.sk_flag + vb0 + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {
-                // owner of the tile's first stage: add the pieces the following workgroups published
+                // owner of the tile's first stage: add the pieces the following workgroups published.
+                // Hand-off (MI355X_MICROARCH.md, inter-workgroup visibility): producer = sc1 write-through
+                // stores, every wave's vmcnt(0), workgroup barrier, flag; consumer = ONE relaxed poll, ONE agent
+                // acquire (this CU's L1), vmcnt(0), workgroup barrier, then the loads (kept sc1: L2-served).
                 int e = cur, k = slot + 1;
                 while (e < (tl + 1) * nst) {
                     if (tid == 0) {
                         int spins = 0;       // bounded: a lost piece must never hang the GPU
                         while (__hip_atomic_load(p.sk_flag + vb0 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 &&
-                               ++spins < (1 << 22))
+                               ++spins < p.sk_spin)
                             __builtin_amdgcn_s_sleep(8);
-                        if (spins >= (1 << 22)) __hip_atomic_store(p.sk_flag + G, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const int ok = spins < p.sk_spin;
+                        // gave up: the piece stays OUT of the sum (its buffer holds an older launch's data) and the
+                        // error word makes the run invalid for the host (uavsal_guard poisons the outputs)
+                        if (!ok) __hip_atomic_fetch_or(p.err, UAVSAL_ERR_STREAMK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        sk_piece_ok = ok;
+#if UAVSAL_SK_ACQUIRE
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
                     }
                     __syncthreads();
+                    const bool have = sk_piece_ok != 0;
                     const float* part = p.sk_part + (size_t)(vb0 + k) * (BM * BN);
+                    if (have) {
 #pragma unroll
                     for (int i = 0; i < WM; ++i) {
                         f32x4 t[WN * 4];
@@ -906,8 +927,10 @@ __global__ __launch_bounds__(256, SK ? 2 : ((WM * WN >= 4) ? 3 : 4)) void conv_g
 #pragma unroll
                             for (int c = 0; c < 4; ++c) acc[i][n >> 2][4 * (n & 3) + c] += t[n][c];
                     }
+                    }
                     __syncthreads();
-                    if (tid == 0) __hip_atomic_store(p.sk_flag + vb0 + k, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (tid == 0 && have)
+                        __hip_atomic_store(p.sk_flag + vb0 + k, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     e = bound(k + 1);
                     ++k;
                 }
@@ -998,8 +1021,12 @@ int launch_variant(const ConvK& k0, int taps, hipStream_t stream) {
 }
 
 // stream-K is used when whole-tile scheduling would leave part of the chip idle in the last round;
-// grid = 2 workgroups per CU (measured best for these shapes), never more than are resident at once
-// (a workgroup may wait for a piece that a higher-numbered one computes first)
+// grid = 2 workgroups per CU (measured best for these shapes), capped at what is resident when the
+// launch has the chip to itself.  Progress does not rest on residency (other lanes' kernels take CUs too):
+// a workgroup publishes the piece it owes BEFORE it waits, and only waits for higher block ids, so a
+// waiting workgroup's producer is either resident (and publishes without waiting) or not yet started
+// (and starts as soon as any workgroup -- of any kernel -- retires).  That needs in-order workgroup dispatch,
+// which the hardware does and HIP does not promise: hence the bounded wait + error word in the kernel.
 static inline int streamk_grid(long long nblk, int kstages, int cus, int cap, bool small_tile) {
     int G = 2 * cus;
     if (G > cap) G = cap;
@@ -1224,7 +1251,9 @@ extern "C" int uavsal_conv_gemm(const uavsal_conv_desc* d, uavsal_stream_t strea
     k.act = d->act; k.epi = d->epi;
     k.contig = ((k.a_is == HW || k.dw_w) && k.o_is == HW && k.r_is == HW && k.x_is == HW) ? 1 : 0;
     k.tiles_n = 0; k.nblk = 0;
-    k.sk_part = nullptr; k.sk_flag = nullptr;
+    k.sk_part = nullptr; k.sk_flag = nullptr; k.err = nullptr;
+    k.sk_spin = d->sk_spin_limit > 0 ? d->sk_spin_limit : (1 << 22);
+    k.sk_drop = d->sk_debug_drop;
     int tile = (d->tile >= 1 && d->tile <= 6) ? d->tile : pick_tile(M, d->Cout, d->prec);
     if (tile == 6) {   // the 256 x 256 tile only carries the vector epilogue
         const bool vec = d->epi == UAVSAL_EPI_AFFINE && d->act != UAVSAL_ACT_SIGMOID && !(d->ldc & 3) &&
@@ -1240,6 +1269,7 @@ extern "C" int uavsal_conv_gemm(const uavsal_conv_desc* d, uavsal_stream_t strea
             // workspace: 64 KB of flags (one per workgroup + a "wait gave up" word), then the partial tiles
             k.sk_flag = (int*)d->sk_ws;
             k.sk_part = (float*)((char*)d->sk_ws + 65536);
+            k.err = d->err ? d->err : (int*)d->sk_ws + (65536 / 4 - 1);
             const bool t1 = d->taps == 1;
             if (tile == 1) return t1 ? SkBig::launch<1>(k, G, s) : SkBig::launch<9>(k, G, s);
             if (tile == 3) return t1 ? SkThin::launch<1>(k, G, s) : SkThin::launch<9>(k, G, s);

@@ -274,3 +274,53 @@ extern "C" int uavsal_layout(const uavsal_layout_desc* d, uavsal_stream_t stream
     hipLaunchKernelGGL(layout_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, k);
     return uavsal_launch_status();
 }
+
+// ---------------------------------------------------------------- error guard (see uavsal_hip.h)
+namespace {
+__global__ __launch_bounds__(256) void guard_kernel(const uavsal_guard_desc d) {
+    const int e = *d.err;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && d.host_err)
+        __hip_atomic_store(d.host_err, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (e == 0) return;
+    const float qnan = __builtin_nanf("");
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        if (!d.buf[b]) continue;
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < d.n[b]; i += (long long)gridDim.x * 256)
+            d.buf[b][i] = qnan;
+    }
+}
+}  // namespace
+
+extern "C" int uavsal_guard(const uavsal_guard_desc* d, uavsal_stream_t stream) {
+    if (!d || !d->err) return UAVSAL_EINVAL;
+    for (int b = 0; b < 3; ++b)
+        if ((d->buf[b] == nullptr) != (d->n[b] == 0) || d->n[b] < 0) return UAVSAL_EINVAL;
+    hipLaunchKernelGGL(guard_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, *d);
+    return uavsal_launch_status();
+}
+
+// ---------------------------------------------------------------- strided row copy (see uavsal_hip.h)
+namespace {
+__global__ __launch_bounds__(256) void copy_rows_kernel(const uavsal_copy_desc d) {
+    const long long per_row = d.row_floats >> 2;
+    const long long total = per_row * d.rows;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / per_row, c = i - r * per_row;
+        *reinterpret_cast<f32x4*>(d.out + r * d.out_pitch + c * 4) =
+            *reinterpret_cast<const f32x4*>(d.in + r * d.in_pitch + c * 4);
+    }
+}
+}  // namespace
+
+extern "C" int uavsal_copy_rows(const uavsal_copy_desc* d, uavsal_stream_t stream) {
+    if (!d || !d->in || !d->out || d->rows <= 0 || d->row_floats <= 0) return UAVSAL_EINVAL;
+    if ((d->row_floats & 3) || (d->in_pitch & 3) || (d->out_pitch & 3) || !uavsal_aligned16(d->in) || !uavsal_aligned16(d->out))
+        return UAVSAL_EALIGN;
+    if (d->in_pitch < d->row_floats || d->out_pitch < d->row_floats) return UAVSAL_ESHAPE;
+    const long long total = (d->row_floats >> 2) * d->rows;
+    long long nblk = (total + 255) / 256;
+    if (nblk > 2048) nblk = 2048;
+    hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, *d);
+    return uavsal_launch_status();
+}

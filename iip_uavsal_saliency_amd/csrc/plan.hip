@@ -8,7 +8,7 @@
 #include "common.h"
 
 namespace {
-enum OpKind { OP_CONV = 0, OP_DW, OP_STEM, OP_BILINEAR, OP_TDIFF, OP_TSUM, OP_LAYOUT, OP_FORK, OP_JOIN };
+enum OpKind { OP_CONV = 0, OP_DW, OP_STEM, OP_BILINEAR, OP_TDIFF, OP_TSUM, OP_LAYOUT, OP_GUARD, OP_COPY, OP_FORK, OP_JOIN };
 constexpr int MAX_LANES = 8;
 
 // Lanes: lane 0 is the caller's stream; lanes 1..7 are private streams on which independent
@@ -27,6 +27,8 @@ struct Op {
         uavsal_tdiff_desc td;
         uavsal_tsum_desc ts;
         uavsal_layout_desc lay;
+        uavsal_guard_desc guard;
+        uavsal_copy_desc copy;
     } u;
 };
 
@@ -39,6 +41,8 @@ int run_op(const Op& op, uavsal_stream_t s) {
         case OP_TDIFF: return uavsal_tdiff(&op.u.td, s);
         case OP_TSUM: return uavsal_tsum(&op.u.ts, s);
         case OP_LAYOUT: return uavsal_layout(&op.u.lay, s);
+        case OP_GUARD: return uavsal_guard(&op.u.guard, s);
+        case OP_COPY: return uavsal_copy_rows(&op.u.copy, s);
     }
     return UAVSAL_EINVAL;
 }
@@ -52,9 +56,67 @@ struct uavsal_plan {
     bool lanes_on = true;
     hipStream_t side[MAX_LANES] = {};
     std::vector<hipEvent_t> events;      // one per fork/join op, created on first use
+    // error reporting: a device word the kernels OR UAVSAL_ERR_* into, a device-visible host mirror that the
+    // guard op fills, and an event recorded after every full run so the host can wait for exactly that run
+    int32_t* err_dev = nullptr;
+    int32_t* err_host = nullptr;          // hipHostMalloc'ed (mapped)
+    int32_t* err_host_dev = nullptr;      // its device address
+    hipEvent_t done = nullptr;
+    bool ran = false;
 };
 
 extern "C" uavsal_plan* uavsal_plan_create(void) { return new (std::nothrow) uavsal_plan(); }
+
+// the error words are allocated on first use, so that a plan can be created (and inspected) without a device
+static bool ensure_error_words(uavsal_plan* p) {
+    if (p->err_dev && p->err_host && p->done) return true;
+    bool ok = hipMalloc((void**)&p->err_dev, 64) == hipSuccess && hipMemset(p->err_dev, 0, 64) == hipSuccess &&
+              hipHostMalloc((void**)&p->err_host, 64, hipHostMallocMapped) == hipSuccess;
+    if (ok) {
+        p->err_host[0] = 0;
+        ok = hipHostGetDevicePointer((void**)&p->err_host_dev, p->err_host, 0) == hipSuccess &&
+             hipEventCreateWithFlags(&p->done, hipEventDisableTiming) == hipSuccess;
+    }
+    if (!ok) (void)hipGetLastError();
+    return ok;
+}
+
+extern "C" int32_t* uavsal_plan_error_word(uavsal_plan* p) { return (p && ensure_error_words(p)) ? p->err_dev : nullptr; }
+
+extern "C" int uavsal_plan_add_guard(uavsal_plan* p, float* b0, int64_t n0, float* b1, int64_t n1, float* b2, int64_t n2) {
+    if (!p) return UAVSAL_EINVAL;
+    if (p->exec) return UAVSAL_ESTATE;
+    if (!ensure_error_words(p)) return UAVSAL_ESTATE;
+    Op op; op.kind = OP_GUARD; op.lane = 0;
+    op.u.guard.err = p->err_dev; op.u.guard.host_err = p->err_host_dev;
+    op.u.guard.buf[0] = b0; op.u.guard.n[0] = n0;
+    op.u.guard.buf[1] = b1; op.u.guard.n[1] = n1;
+    op.u.guard.buf[2] = b2; op.u.guard.n[2] = n2;
+    for (int b = 0; b < 3; ++b)
+        if ((op.u.guard.buf[b] == nullptr) != (op.u.guard.n[b] == 0) || op.u.guard.n[b] < 0) return UAVSAL_EINVAL;
+    p->ops.push_back(op);
+    return (int)p->ops.size() - 1;
+}
+
+extern "C" int uavsal_plan_status(uavsal_plan* p, int wait) {
+    if (!p) return UAVSAL_EINVAL;
+    if (!p->ran) return 0;
+    if (wait) {
+        const hipError_t e = hipEventSynchronize(p->done);
+        if (e != hipSuccess) return (int)e;
+    } else {
+        const hipError_t e = hipEventQuery(p->done);
+        if (e == hipErrorNotReady) { (void)hipGetLastError(); return 0; }
+        if (e != hipSuccess) return (int)e;
+    }
+    const int32_t code = *(volatile int32_t*)p->err_host;
+    if (code == 0) return 0;
+    // rare path: clear both words (the run is over: the event has completed) and report once
+    p->err_host[0] = 0;
+    const hipError_t e = hipMemset(p->err_dev, 0, 64);
+    if (e != hipSuccess) return (int)e;
+    return UAVSAL_EDEVICE;
+}
 
 extern "C" void uavsal_plan_destroy(uavsal_plan* p) {
     if (!p) return;
@@ -62,6 +124,9 @@ extern "C" void uavsal_plan_destroy(uavsal_plan* p) {
     if (p->graph) hipGraphDestroy(p->graph);
     for (hipEvent_t e : p->events) if (e) hipEventDestroy(e);
     for (int i = 1; i < MAX_LANES; ++i) if (p->side[i]) hipStreamDestroy(p->side[i]);
+    if (p->done) hipEventDestroy(p->done);
+    if (p->err_host) hipHostFree(p->err_host);
+    if (p->err_dev) hipFree(p->err_dev);
     delete p;
 }
 
@@ -103,6 +168,7 @@ UAVSAL_ADD(uavsal_plan_add_bilinear, OP_BILINEAR, bil, uavsal_bilinear_desc)
 UAVSAL_ADD(uavsal_plan_add_tdiff, OP_TDIFF, td, uavsal_tdiff_desc)
 UAVSAL_ADD(uavsal_plan_add_tsum, OP_TSUM, ts, uavsal_tsum_desc)
 UAVSAL_ADD(uavsal_plan_add_layout, OP_LAYOUT, lay, uavsal_layout_desc)
+UAVSAL_ADD(uavsal_plan_add_copy, OP_COPY, copy, uavsal_copy_desc)
 
 extern "C" int uavsal_plan_size(const uavsal_plan* p) { return p ? (int)p->ops.size() : UAVSAL_EINVAL; }
 
@@ -135,6 +201,15 @@ extern "C" int uavsal_plan_run(uavsal_plan* p, int first, int last, uavsal_strea
         const int e = run_op(op, s);
         if (e) return e;
     }
+    if (first == 0 && last == n) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(main_s, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+        if (cs == hipStreamCaptureStatusNone && p->done) {     // (a captured run is marked by uavsal_plan_graph_launch)
+            const hipError_t e = hipEventRecord(p->done, main_s);
+            if (e != hipSuccess) return (int)e;
+            p->ran = true;
+        }
+    }
     return 0;
 }
 
@@ -159,7 +234,11 @@ extern "C" int uavsal_plan_graph_build(uavsal_plan* p, uavsal_stream_t stream) {
 extern "C" int uavsal_plan_graph_launch(uavsal_plan* p, uavsal_stream_t stream) {
     if (!p) return UAVSAL_EINVAL;
     if (!p->exec) return UAVSAL_ESTATE;
-    const hipError_t e = hipGraphLaunch(p->exec, (hipStream_t)stream);
+    hipError_t e = hipGraphLaunch(p->exec, (hipStream_t)stream);
+    if (e == hipSuccess && p->done) {
+        e = hipEventRecord(p->done, (hipStream_t)stream);
+        if (e == hipSuccess) p->ran = true;
+    }
     return e == hipSuccess ? 0 : (int)e;
 }
 
@@ -195,6 +274,8 @@ extern "C" int uavsal_sizeof_desc(int which) {
         case 5: return (int)sizeof(uavsal_tsum_desc);
         case 6: return (int)sizeof(uavsal_layout_desc);
         case 7: return (int)sizeof(uavsal_post_desc);
+        case 8: return (int)sizeof(uavsal_guard_desc);
+        case 9: return (int)sizeof(uavsal_copy_desc);
     }
     return UAVSAL_EINVAL;
 }

@@ -53,7 +53,8 @@ class V:
 class Engine:
     def __init__(self, model, device, n_seq, seq_len, H, W, ctx_T, ctx_mode="tile",
                  precision="f32", taps=False, in_dtype=torch.float32, use_graph=False, fuse_dw=None,
-                 use_lanes=True, stream_k=True):
+                 use_lanes=True, stream_k=True, sync_errors=True, persistent=False,
+                 wcache=None):
         if precision not in L.PREC:
             raise ValueError("precision must be one of %s" % list(L.PREC))
         self.lib = L.load()
@@ -69,7 +70,13 @@ class Engine:
         self.in_dtype = in_dtype
         self.use_graph = use_graph
         self.stream_k = bool(stream_k)
+        # device-side errors (a stream-K hand-off that timed out) are never silent: the guard op at the end of
+        # the plan overwrites the outputs with NaN, and `run` raises -- before it returns when `sync_errors`
+        # (one event wait per call), else at the next call / `check()` once the run is known to be over
+        self.sync_errors = bool(sync_errors)
         self._sk_ws = {}
+        self._err = None
+        self._sk_debug = tuple(getattr(model, "_sk_debug", (0, 0)))
         # fused depthwise->projection GEMM (uavsal_conv_desc.dw_*): D never reaches HBM.
         # Measured (profiles/README.md): as written -- nine dependent global loads per staged value, no
         # LDS-staged halo tile -- the fused loader is latency-bound and ~1.5x SLOWER end to end, so it is
@@ -79,8 +86,11 @@ class Engine:
             raise RuntimeError("frame count %d is not a multiple of time_dims %d" % (self.N, ctx_T))
         self.h = _down(_down(_down(H)))
         self.w = _down(_down(_down(W)))
-        self._keep: List[torch.Tensor] = []        # weights / buffers kept alive
-        self._wcache: Dict[int, tuple] = {}
+        self._keep: List[torch.Tensor] = []        # buffers kept alive
+        # packed device weights, keyed by (kind, id(module), ...): one copy per model, shared by its engines
+        self._wcache: Dict[tuple, object] = wcache if wcache is not None else {}
+        # persistent-state mode: the recurrent state lives in `hprev` (NHWC) across calls, see run()
+        self.persistent = bool(persistent)
         self.ops_meta: List[dict] = []
         self.stage_ranges: Dict[str, tuple] = {}
         self.named: Dict[str, V] = {}
@@ -99,6 +109,7 @@ class Engine:
         self.plan = C.c_void_p(self.lib.uavsal_plan_create())
         if not self.plan:
             raise RuntimeError("uavsal_plan_create failed")
+        self._err = self.lib.uavsal_plan_error_word(self.plan)
         self._build()
         self.use_lanes = bool(use_lanes)
         L.check(self.lib.uavsal_plan_enable_lanes(self.plan, 1 if self.use_lanes else 0), "plan_enable_lanes")
@@ -159,12 +170,10 @@ class Engine:
                 L.check(r, "plan_add_join")
 
     def _dev(self, t: torch.Tensor) -> torch.Tensor:
-        d = t.contiguous().to(self.device)
-        self._keep.append(d)
-        return d
+        return t.contiguous().to(self.device)      # kept alive by the weight cache
 
     def _affine(self, bn, cout):
-        key = ("bn", id(bn))
+        key = ("bn", id(bn), cout)
         if key not in self._wcache:
             s, b = P.fold_bn(bn)
             n = P.roundup(cout, 32)
@@ -249,6 +258,8 @@ class Engine:
                 ws = self._sk_ws[self._lane] = torch.zeros(int(self.lib.uavsal_streamk_workspace_bytes()),
                                                            dtype=torch.uint8, device=self.device)
             d.sk_ws, d.sk_ws_bytes = ws.data_ptr(), ws.numel()
+        d.err = self._err
+        d.sk_spin_limit, d.sk_debug_drop = self._sk_debug      # test hooks (model._sk_debug), normally (0, 0)
         self.ops_meta[-1]["tile"] = int(self.lib.uavsal_conv_tile(C.byref(d)))
         self.ops_meta[-1]["streamk"] = int(self.lib.uavsal_conv_streamk_grid(C.byref(d)))
         self._add(self.lib.uavsal_plan_add_conv, d, "plan_add_conv(%s)" % name)
@@ -345,12 +356,16 @@ class Engine:
         g0 = self._buf("gauss_in", N, h, w, 8)
         o0 = self._buf("ob_in", N, h, w, 20)
         if self._dry:
-            for nm, c in (("state.in", 256), ("gauss.in", 8), ("ob.in", 20)) + ((("cstate.in", 256),) if lstm_model else ()):
+            lay = (("gauss.in", 8), ("ob.in", 20))
+            if not self.persistent:
+                lay = (("state.in", 256),) + lay + ((("cstate.in", 256),) if lstm_model else ())
+            for nm, c in lay:
                 self._meta(kind="layout", name=nm, flops=0.0, bytes=8.0 * N * c * hw)
         else:
-            self.layout("state.in", self.state_in.data_ptr(), h0.ptr, self.n_seq, 256, hw, 256, 1)
-            if lstm_model:
-                self.layout("cstate.in", self.cstate_in.data_ptr(), c0.ptr, self.n_seq, 256, hw, 256, 1)
+            if not self.persistent:      # persistent mode: h0 / c0 ARE the state, staged only on demand (run())
+                self.layout("state.in", self.state_in.data_ptr(), h0.ptr, self.n_seq, 256, hw, 256, 1)
+                if lstm_model:
+                    self.layout("cstate.in", self.cstate_in.data_ptr(), c0.ptr, self.n_seq, 256, hw, 256, 1)
             self.layout("gauss.in", self.cb0_in.data_ptr(), g0.ptr, N, 8, hw, 8, 1)
             self.layout("ob.in", self.cb1_in.data_ptr(), o0.ptr, N, 20, hw, 20, 1)
         self._mark("boundary_in", s0)
@@ -379,8 +394,11 @@ class Engine:
                    bytes=(4.0 if self.in_dtype == torch.float32 else 1.0) * N * 3 * self.H * self.W + 4.0 * N * H1 * W1 * 32)
         if not self._dry:
             conv0, bn0 = feats[0][0], feats[0][1]
-            s, b = P.fold_bn(bn0)
-            ws, ss, bs = self._dev(P.pack_stem_weight(conv0.weight)), self._dev(s), self._dev(b)
+            key = ("stem", id(conv0))
+            if key not in self._wcache:
+                s, b = P.fold_bn(bn0)
+                self._wcache[key] = (self._dev(P.pack_stem_weight(conv0.weight)), self._dev(s), self._dev(b))
+            ws, ss, bs = self._wcache[key]
             d = L.StemDesc()
             if self.in_dtype == torch.uint8:
                 d.inp, d.in_u8 = None, self.x_in.data_ptr()
@@ -537,14 +555,39 @@ class Engine:
             lv = V(_Fake() if self._dry else self.logits, N, h, w, 1)
             self.ir_block("conv_out_st.logits", ro, m.conv_out_st, lv, final_act=NONE)
         self.ir_block("conv_out_st", ro, m.conv_out_st, outv, final_act=L.ACT_SIGMOID)
-        outs = [(ro, "state_out")] + ([(self.named["lstm_c"], "cstate_out")] if lstm else [])
-        for c in range(self.n_seq):
-            for hist, dst in outs:
-                last = hist.frames(c * Lq + Lq - 1, 1)
-                if self._dry:
-                    self._meta(kind="layout", name="state.out", flops=0.0, bytes=8.0 * 256 * hw)
-                else:
-                    self.layout("state.out", last.ptr, getattr(self, dst).data_ptr() + 4 * c * 256 * hw, 1, 256, hw, 256, 0)
+        outs = [(ro, "state_out", h0)] + ([(self.named["lstm_c"], "cstate_out", c0)] if lstm else [])
+        if self.persistent:
+            # h_last of every clip (NHWC rows of the history) -> the resident state buffer, one strided copy
+            for hist, _, keep in outs:
+                self._meta(kind="copy", name="state.keep", flops=0.0, bytes=8.0 * self.n_seq * 256 * hw)
+                if not self._dry:
+                    d = L.CopyDesc()
+                    d.inp, d.out = hist.frames(Lq - 1, 1).ptr, keep.ptr
+                    d.in_pitch, d.out_pitch, d.row_floats, d.rows = Lq * hw * 256, hw * 256, hw * 256, self.n_seq
+                    self._add(self.lib.uavsal_plan_add_copy, d, "plan_add_copy")
+        else:
+            for c in range(self.n_seq):
+                for hist, dst, _ in outs:
+                    last = hist.frames(c * Lq + Lq - 1, 1)
+                    if self._dry:
+                        self._meta(kind="layout", name="state.out", flops=0.0, bytes=8.0 * 256 * hw)
+                    else:
+                        self.layout("state.out", last.ptr, getattr(self, dst).data_ptr() + 4 * c * 256 * hw, 1, 256, hw, 256, 0)
+        # error guard: poisons what the caller will see if any kernel of this run set the error word
+        self._meta(kind="guard", name="guard", flops=0.0, bytes=0.0)
+        if not self._dry:
+            bufs = [(self.out.data_ptr(), self.out.numel())]
+            if self.persistent:
+                bufs.append((h0.ptr, self.n_seq * hw * 256))
+                bufs.append((c0.ptr, self.n_seq * hw * 256) if lstm else (None, 0))
+                # what the caller gets back: channels-last views of the resident buffers
+                self.h_view = h0.t.view(self.n_seq, h, w, 256).permute(0, 3, 1, 2)
+                self.c_view = c0.t.view(self.n_seq, h, w, 256).permute(0, 3, 1, 2) if lstm else None
+            else:
+                bufs.append((self.state_out.data_ptr(), self.state_out.numel()))
+                r = self.lib.uavsal_plan_add_guard(self.plan, bufs[0][0], bufs[0][1], bufs[1][0], bufs[1][1], bufs[2][0], bufs[2][1])
+            if r < 0:
+                L.check(r, "plan_add_guard")
         self._mark("decoder", s0)
 
     # ------------------------------------------------------------------ execution
@@ -572,10 +615,35 @@ class Engine:
         else:
             L.check(self.lib.uavsal_plan_run(self.plan, 0, -1, self._stream()), "plan_run")
 
+    def _is_resident(self, t, view) -> bool:
+        return (t is not None and view is not None and t.data_ptr() == view.data_ptr()
+                and t.numel() == view.numel() and t.reshape(view.shape).stride() == view.stride())
+
+    def _stage_state_persistent(self, state, cstate):
+        """Persistent mode: the caller's state is already resident when it is the view `run` returned (or a
+        detach of it, Demo_Test.py:86); None resets it (model_convlstm.py:356); any other tensor is loaded."""
+        pairs = [(state, self.h_view, self.state_in, "h0")]
+        if self.c_view is not None:
+            pairs.append((cstate, self.c_view, self.cstate_in, "c0"))
+        for t, view, stage, name in pairs:
+            if self._is_resident(t, view):
+                continue
+            buf = self.named[name]
+            if t is None:
+                buf.t.zero_()
+                continue
+            stage.copy_(t.reshape(stage.shape))
+            d = L.LayoutDesc()
+            d.inp, d.out, d.n_img, d.C, d.HW, d.ld, d.to_nhwc, d.Cpad = (
+                stage.data_ptr(), buf.ptr, self.n_seq, 256, self.h * self.w, 256, 1, 0)
+            L.check(self.lib.uavsal_layout(C.byref(d), self._stream()), "uavsal_layout(state)")
+
     def stage_inputs(self, x, cb0, cb1, state, cstate=None):
         self.x_in.copy_(x.reshape(self.x_in.shape))
         self.cb0_in.copy_(cb0.reshape(self.cb0_in.shape))
         self.cb1_in.copy_(cb1.reshape(self.cb1_in.shape))
+        if self.persistent:
+            return self._stage_state_persistent(state, cstate)
         if state is None:
             self.state_in.zero_()
         else:
@@ -589,12 +657,19 @@ class Engine:
         if x.dtype != self.in_dtype:
             raise RuntimeError("engine built for %s frames, got %s" % (self.in_dtype, x.dtype))
         with torch.cuda.device(self.device):
+            self.check(wait=False)               # a previous asynchronous run that is over by now
             self.stage_inputs(x, cb0, cb1, state, cstate)
             self.launch()
+            if self.sync_errors:
+                self.check(wait=True)
             out = self.out.clone()
-            st = self.state_out.clone()
-            if getattr(self.model, "rnn_type", "twa") == "lstm":
-                st = (st, self.cstate_out.clone())
+            lstm = getattr(self.model, "rnn_type", "twa") == "lstm"
+            if self.persistent:          # opt-in aliasing: views of the resident state, overwritten by the next call
+                st = (self.h_view, self.c_view) if lstm else self.h_view
+            else:
+                st = self.state_out.clone()
+                if lstm:
+                    st = (st, self.cstate_out.clone())
             if taps is not None:
                 if not self.keep_taps:
                     raise RuntimeError("engine was built without taps")
@@ -602,6 +677,21 @@ class Engine:
                     taps[k] = self.tap(k)
                 taps["logits"] = self.logits.clone().view(self.N, 1, self.h, self.w)
         return out, st
+
+    def check(self, wait=True):
+        """Raise if the most recent run reported a device-side error (its outputs were overwritten with NaN).
+        `wait=False` only looks when that run is known to have finished."""
+        code = self.lib.uavsal_plan_status(self.plan, 1 if wait else 0)
+        if code == 0:
+            return
+        if code == -5:
+            # a piece published after its owner gave up would be consumed by the next launch: start clean
+            torch.cuda.synchronize(self.device)
+            for ws in self._sk_ws.values():
+                ws[:65536].zero_()
+            raise RuntimeError("UAVSal HIP path: a stream-K hand-off timed out on the device "
+                               "(UAVSAL_ERR_STREAMK); the maps and state of that call are invalid (NaN-filled)")
+        L.check(code, "uavsal_plan_status")
 
     def streamk_clean(self) -> bool:
         """True when the stream-K workspace's flag block is all zero, as every launch must leave it (a set

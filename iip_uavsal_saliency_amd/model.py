@@ -17,6 +17,7 @@ fed to the matrix cores ('f32' exact fp32 MFMA, 'bf16x3' split-bf16, 'bf16').
 from __future__ import annotations
 
 import os
+from collections import OrderedDict
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -165,6 +166,17 @@ class UAVSal(nn.Module):
         self.fuse_dw = None             # None: engine default (off; see engine.py)
         self.use_lanes = True           # independent branches on parallel streams / graph branches
         self.stream_k = True            # fp32 GEMMs: split K across workgroups when whole tiles leave CUs idle
+        # A device-side error (a stream-K hand-off that timed out) always NaN-fills the returned map and state.
+        # True: forward also waits for its own launches (one event wait) and raises before returning;
+        # False: fully asynchronous, the RuntimeError comes from the next forward / `check_errors()`.
+        self.sync_errors = True
+        # Opt-in persistent recurrent state (SURVEY.md 8(b) "Ownership", BASELINE configs[4]): the state stays
+        # in the engine's NHWC buffer between calls; the returned state is a channels-last VIEW of that buffer
+        # (valid until the next call overwrites it) and passing it back costs nothing.  Default False keeps the
+        # reference's ownership rule: fresh tensors, never aliased (Demo_Test.py:86).
+        self.persistent_state = False
+        self.max_engines = 4            # launch plans kept per model (LRU); packed weights are shared by all
+        self.check_weight_versions = True   # rebuild plans when a parameter/buffer was modified in place
         self.sfnet = uavsal_srfnet_aspp(cnn_type, last_channel=planes)
         self.num_stblock = num_stblock
         self.st_layer = nn.Sequential(*[
@@ -190,13 +202,29 @@ class UAVSal(nn.Module):
         init_weights(self.st_layer, "kaiming_normal", mode="fan_out")
         init_weights(self.fust_layer, "kaiming_normal", mode="fan_out")
         init_weights(self.conv_out_st, "kaiming_normal", mode="fan_out")
-        self._engines: Dict[tuple, "object"] = {}
+        self._engines: "OrderedDict[tuple, object]" = OrderedDict()
+        self._wshared: Dict[tuple, object] = {}      # packed device weights, shared by every engine
+        self._wversion = None
         if pre_model_path and os.path.exists(pre_model_path):
-            self.load_state_dict(torch.load(pre_model_path, map_location="cpu").state_dict(), strict=False)
+            # the reference's checkpoints are whole pickled models (model.py:339): resolved through the shim
+            from .checkpoint import load_reference_state_dict
+            self.load_state_dict(load_reference_state_dict(pre_model_path), strict=False)
 
     # -- engines are built from the current parameter values; drop them when those change
     def _drop_engines(self):
-        self._engines = {}
+        self._engines = OrderedDict()
+        self._wshared = {}
+        self._wversion = None
+
+    invalidate_engines = _drop_engines
+
+    def _weights_version(self):
+        return sum(t._version for t in self._wtensors)
+
+    def check_errors(self):
+        """Wait for every launched forward and raise if one reported a device-side error."""
+        for eng in list(self._engines.values()):
+            eng.check(wait=True)
 
     def load_state_dict(self, *args, **kwargs):
         out = super().load_state_dict(*args, **kwargs)
@@ -215,16 +243,31 @@ class UAVSal(nn.Module):
 
     def _engine(self, device, n_seq, seq_len, H, W, ctx_mode, taps=False, in_dtype=torch.float32):
         from .engine import Engine
+        if self.check_weight_versions:
+            if self._wversion is None:
+                self._wtensors = [t for k, t in self.state_dict(keep_vars=True).items()
+                                  if not k.endswith("num_batches_tracked")]
+                self._wversion = self._weights_version()
+            elif self._weights_version() != self._wversion:      # param.data.copy_(...), an optimizer step, ...
+                self._drop_engines()
+                return self._engine(device, n_seq, seq_len, H, W, ctx_mode, taps, in_dtype)
         key = (str(device), n_seq, seq_len, H, W, self.time_dims if ctx_mode == "tile" else seq_len,
                ctx_mode, self.precision, bool(taps), in_dtype, bool(self.use_graph), self.rnn_type, self.fuse_dw, bool(self.use_lanes),
-               bool(self.stream_k))
+               bool(self.stream_k), bool(self.persistent_state), tuple(getattr(self, "_sk_debug", (0, 0))))
         eng = self._engines.get(key)
         if eng is None:
+            while len(self._engines) >= max(1, int(self.max_engines)):
+                _, old = self._engines.popitem(last=False)       # least recently used
+                old.check(wait=True)
             eng = Engine(self, device, n_seq=n_seq, seq_len=seq_len, H=H, W=W,
                          ctx_T=key[5], ctx_mode=ctx_mode, precision=self.precision, taps=taps,
                          in_dtype=in_dtype, use_graph=self.use_graph, fuse_dw=self.fuse_dw,
-                         use_lanes=self.use_lanes, stream_k=self.stream_k)
+                         use_lanes=self.use_lanes, stream_k=self.stream_k, persistent=self.persistent_state,
+                         wcache=self._wshared)
             self._engines[key] = eng
+        else:
+            self._engines.move_to_end(key)
+        eng.sync_errors = bool(self.sync_errors)
         return eng
 
     def _check_common(self, x):
@@ -262,6 +305,8 @@ class UAVSal(nn.Module):
                 st, cst = st
             if tuple(st.shape) != (1, 256, h, w) or (cst is not None and tuple(cst.shape) != (1, 256, h, w)):
                 raise RuntimeError("in_state tensors must be [1, 256, %d, %d]" % (h, w))
+            if st.dtype != torch.float32 or st.device != x.device:
+                raise RuntimeError("in_state must be float32 on the frames' device")
         out, state = eng.run(x, cb[0], cb[1], st, taps, cstate=cst)
         if self.rnn_type == "lstm":               # reference returns last_state_list[-1] = [h, c]
             return out.view(n, 1, h, w), [state[0].view(1, 256, h, w), state[1].view(1, 256, h, w)]

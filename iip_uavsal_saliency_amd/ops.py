@@ -32,8 +32,19 @@ def _nhwc_view(t: torch.Tensor):
     return t.data_ptr(), ld, n, h, w, c
 
 
+def _streamk_outcome(ws, what):
+    """After a synchronised stream-K launch: the error word (last int of the flag block when the descriptor
+    carries no `err` pointer) must be clear and every flag reset."""
+    flags = ws[:65536].view(torch.int32)
+    if int(flags[-1].item()) != 0:
+        ws[:65536].zero_()
+        raise RuntimeError("%s: a stream-K hand-off timed out on the device (UAVSAL_ERR_STREAMK)" % what)
+    if int(flags.abs().sum().item()) != 0:
+        raise RuntimeError("stream-K workspace not clean after the launch")
+
+
 def conv_gemm(x, weight, scale=None, bias=None, act=L.ACT_NONE, res=None, out=None, prec="f32", tile=0, dw=None,
-              stream_k=False):
+              stream_k=False, sk_spin_limit=0, sk_debug_drop=0):
     """Dense 1x1 / 3x3 conv (+ folded BN, activation, residual).  `weight` [Cout,Cin,k,k] (cpu or cuda).
     `dw=(w[C,1,3,3], scale[C], bias[C], stride)`: x is the expanded tensor and the depthwise 3x3 + BN + ReLU6
     in front of this 1x1 conv is computed inside the GEMM's loader (fused inverted-residual tail)."""
@@ -72,13 +83,11 @@ def conv_gemm(x, weight, scale=None, bias=None, act=L.ACT_NONE, res=None, out=No
         ws = torch.zeros(int(lib.uavsal_streamk_workspace_bytes()), dtype=torch.uint8, device=x.device)
         keep.append(ws)
         d.sk_ws, d.sk_ws_bytes = ws.data_ptr(), ws.numel()
+        d.sk_spin_limit, d.sk_debug_drop = sk_spin_limit, sk_debug_drop
     L.check(lib.uavsal_conv_gemm(C.byref(d), _stream(x)), "uavsal_conv_gemm")
     torch.cuda.current_stream(x.device).synchronize()   # `keep` must outlive the launch
     if stream_k:
-        # the kernels leave the workspace zeroed; a set word means a published piece was never consumed,
-        # or the bounded wait for one gave up
-        if int(ws[:65536].view(torch.int32).abs().sum().item()) != 0:      # the flag block (uavsal_hip.h)
-            raise RuntimeError("stream-K workspace not clean after the launch")
+        _streamk_outcome(ws, "uavsal_conv_gemm")
     return out
 
 
@@ -103,8 +112,8 @@ def twa_step(x_t, h_prev, pre_t, w_h, prec="f32", tile=0, stream_k=False):
         d.sk_ws, d.sk_ws_bytes = ws.data_ptr(), ws.numel()
     L.check(lib.uavsal_conv_gemm(C.byref(d), _stream(x_t)), "uavsal_conv_gemm(TWA)")
     torch.cuda.current_stream(x_t.device).synchronize()
-    if stream_k and int(ws[:65536].view(torch.int32).abs().sum().item()) != 0:
-        raise RuntimeError("stream-K workspace not clean after the launch")
+    if stream_k:
+        _streamk_outcome(ws, "uavsal_conv_gemm(TWA)")
     return out
 
 

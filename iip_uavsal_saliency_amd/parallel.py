@@ -60,12 +60,23 @@ def gather_maps(local_out: torch.Tensor, gathered: Optional[torch.Tensor] = None
     return gathered
 
 
-def forward_clips_sharded(model, x_all, cb_all, states_local=None):
-    """Data-parallel `forward_clips`: every rank passes the FULL batch description
-    (`x_all [C,T,3,H,W]`, `cb_all`), computes only its own clips and returns
-    (all maps `[C,T,1,h,w]` gathered on every rank, this rank's states `[C/W,256,h,w]`)."""
+def forward_clips_sharded(model, x, cb, states_local=None, total_clips: Optional[int] = None):
+    """Data-parallel `forward_clips`: this rank computes its own clips and the maps of all ranks are
+    exchanged with one all-gather.
+
+    `x` / `cb` are either this rank's LOCAL shard (`x [C/W,T,3,H,W]`; pass `total_clips=C`) -- the
+    production form: a rank only ever holds 1/W of the frames (configs[3]: 8 of 64 clips, 177 MB of
+    1.4 GB) -- or, with `total_clips=None`, the full batch `[C,T,...]` from which the rank's contiguous
+    block is sliced (convenient for small tests).  `states_local` `[C/W,256,h,w]` never leaves the rank.
+    Returns (all maps `[C,T,1,h,w]` gathered on every rank in clip order, this rank's states)."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
-    sh = ClipShard(x_all.shape[0], world, rank)
-    out, st = model.forward_clips(sh.local(x_all), [sh.local(cb_all[0]), sh.local(cb_all[1])], states_local)
+    if total_clips is None:
+        sh = ClipShard(x.shape[0], world, rank)
+        x, cb = sh.local(x), [sh.local(cb[0]), sh.local(cb[1])]
+    else:
+        sh = ClipShard(total_clips, world, rank)
+        if x.shape[0] != sh.count or cb[0].shape[0] != sh.count or cb[1].shape[0] != sh.count:
+            raise RuntimeError("rank %d owns %d of %d clips, got a shard of %d" % (rank, sh.count, total_clips, x.shape[0]))
+    out, st = model.forward_clips(x, cb, states_local)
     return gather_maps(out), st

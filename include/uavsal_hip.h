@@ -35,13 +35,18 @@
 extern "C" {
 #endif
 
-#define UAVSAL_ABI_VERSION 7
+#define UAVSAL_ABI_VERSION 8
 
 /* argument errors */
 #define UAVSAL_EINVAL   (-1)  /* null pointer / non-positive size */
 #define UAVSAL_EALIGN   (-2)  /* channel count / ld / pointer not 16-byte aligned */
 #define UAVSAL_ESHAPE   (-3)  /* shape not supported by the kernel (see entry point) */
 #define UAVSAL_ESTATE   (-4)  /* plan used in the wrong state */
+#define UAVSAL_EDEVICE  (-5)  /* a kernel reported that it could not complete its work (uavsal_conv_desc.err):
+                                 the outputs of that run are invalid and were overwritten with NaN */
+
+/* bits of the device error word (uavsal_conv_desc.err) */
+#define UAVSAL_ERR_STREAMK  1 /* a stream-K owner gave up waiting for a partial tile another workgroup owed it */
 
 /* GEMM operand precision (how fp32 activations/weights are fed to the matrix cores) */
 #define UAVSAL_PREC_F32     0 /* v_mfma_f32_32x32x2_f32: exact fp32 fma chain */
@@ -126,8 +131,17 @@ typedef struct uavsal_conv_desc {
      * memory, 16-byte aligned, ZERO-filled once by the caller and then owned by launches that are ordered
      * on one stream (the kernels leave it zeroed).  With it, launches whose tile count would idle part of
      * the chip in the last round split the K loop of some tiles across workgroups; the summation order
-     * stays a function of the shape only.  NULL = whole-tile scheduling. */
+     * stays a function of the shape only.  NULL = whole-tile scheduling.
+     * Progress: a workgroup computes the piece it owes another tile BEFORE it waits for anything, and it only
+     * ever waits for workgroups with a higher block id, so the launch completes whenever the hardware starts
+     * workgroups in block order (it does; HIP does not promise it).  The wait is therefore bounded
+     * (`sk_spin_limit` polls): an owner that gives up leaves the missing piece OUT of its sum and sets
+     * UAVSAL_ERR_STREAMK in `*err` -- the caller must treat the output as invalid and re-zero the flag block
+     * (uavsal_guard / uavsal_plan_status do both checks for a plan). */
     void* sk_ws; int64_t sk_ws_bytes;
+    int32_t* err;            /* device word OR-ed with UAVSAL_ERR_* (NULL: the last int32 of sk_ws' 64 KB flag block) */
+    int32_t sk_spin_limit;   /* polls before a stream-K owner gives up on one piece; 0 = default (1 << 22, seconds) */
+    int32_t sk_debug_drop;   /* TEST HOOK: 1 + index of the stream-K workgroup that withholds its "published" flag (< 0: all do); 0 = none */
 } uavsal_conv_desc;
 
 int uavsal_conv_gemm(const uavsal_conv_desc* d, uavsal_stream_t stream);
@@ -241,6 +255,34 @@ typedef struct uavsal_post_desc {
 
 int uavsal_postprocess(const uavsal_post_desc* d, uavsal_stream_t stream);
 
+/*
+ * Strided row copy, device to device: `rows` rows of `row_floats` contiguous floats (a multiple of 4),
+ * row r read at in + r*in_pitch and written at out + r*out_pitch (pitches in floats).  Used by the
+ * persistent-state mode to carry h_last (NHWC, last frame of every clip of the ConvTWA history, which
+ * IS the state: model_convlstm.py:377-381) into the resident state buffer that step 0 of the next call
+ * reads -- the device-side form of `x_state = [out_state[0].detach()]` (Demo_Test.py:86).
+ */
+typedef struct uavsal_copy_desc {
+    const float* in;  float* out;
+    int64_t in_pitch, out_pitch, row_floats;  int32_t rows;
+} uavsal_copy_desc;
+
+int uavsal_copy_rows(const uavsal_copy_desc* d, uavsal_stream_t stream);
+
+/*
+ * Error guard: the last launch of a forward.  If `*err` is non-zero (a kernel of this run reported
+ * UAVSAL_ERR_*), every listed buffer is overwritten with NaN, so that no caller can mistake the result
+ * for a saliency map; `*err` is then copied to `*host_err` (a device-visible host word, may be NULL).
+ * The caller-facing contract (SURVEY.md 8(b) "Errors: never silent") is completed on the host by
+ * uavsal_plan_status.
+ */
+typedef struct uavsal_guard_desc {
+    const int32_t* err;  int32_t* host_err;
+    float* buf[3];  int64_t n[3];          /* fp32 buffers to poison; unused entries NULL / 0 */
+} uavsal_guard_desc;
+
+int uavsal_guard(const uavsal_guard_desc* d, uavsal_stream_t stream);
+
 /* ---- launch plan: a recorded sequence of the calls above, run natively ------------ */
 typedef struct uavsal_plan uavsal_plan;
 
@@ -253,6 +295,16 @@ int uavsal_plan_add_bilinear(uavsal_plan* p, const uavsal_bilinear_desc* d);
 int uavsal_plan_add_tdiff(uavsal_plan* p, const uavsal_tdiff_desc* d);
 int uavsal_plan_add_tsum(uavsal_plan* p, const uavsal_tsum_desc* d);
 int uavsal_plan_add_layout(uavsal_plan* p, const uavsal_layout_desc* d);
+int uavsal_plan_add_copy(uavsal_plan* p, const uavsal_copy_desc* d);
+/* The plan owns one device error word (for uavsal_conv_desc.err of its convs) and a host mirror of it.
+ * add_guard records a uavsal_guard over up to three output buffers with those words filled in. */
+int32_t* uavsal_plan_error_word(uavsal_plan* p);
+int uavsal_plan_add_guard(uavsal_plan* p, float* b0, int64_t n0, float* b1, int64_t n1, float* b2, int64_t n2);
+/* Outcome of the most recent uavsal_plan_run / uavsal_plan_graph_launch: 0 = completed without a device
+ * error (or, with wait == 0, still running); UAVSAL_EDEVICE = a kernel set the error word (returned
+ * once: the words are cleared; the caller re-zeroes its stream-K workspaces).  wait != 0 blocks until
+ * the run has finished. */
+int uavsal_plan_status(uavsal_plan* p, int wait);
 /* Parallel branches: ops are recorded on the current lane (0 = the caller's stream, 1..7 = private
  * streams).  fork(l): lane l starts after everything recorded on lane 0 so far; join(l): lane 0 waits
  * for lane l.  Every forked lane must be joined before the plan ends.  A captured plan keeps the
@@ -274,7 +326,7 @@ int uavsal_plan_graph_launch(uavsal_plan* p, uavsal_stream_t stream);
 int uavsal_plan_time(uavsal_plan* p, int first, int last, int iters, uavsal_stream_t stream, float* ms);
 
 int uavsal_abi_version(void);
-int uavsal_sizeof_desc(int which); /* 0 conv,1 dw,2 stem,3 bilinear,4 tdiff,5 tsum,6 layout,7 post */
+int uavsal_sizeof_desc(int which); /* 0 conv,1 dw,2 stem,3 bilinear,4 tdiff,5 tsum,6 layout,7 post,8 guard,9 copy */
 const char* uavsal_build_info(void);
 
 #ifdef __cplusplus

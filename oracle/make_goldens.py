@@ -132,6 +132,55 @@ def run_case(ref_model, name, H, W, T, B=1, seed=0, tap_stride=13, state_stride=
         os.path.getsize(path) / 1024))
 
 
+def clip_inputs(C, T, H, W, seed=0, t0=0):
+    """C independent clips, clip c seeded with seed + c (the convention of bench.py make_clips and
+    tests/test_hip_e2e.py): x [C,T,3,H,W], cb [[C,T,8,h,w],[C,T,20,h,w]]."""
+    h, w = H // 8, W // 8
+    xs, g, o = [], [], []
+    for c in range(C):
+        xs.append(torch.from_numpy(synth.normalize_frames(synth.synth_frames_u8(T, H, W, seed + c, t0))))
+        g.append(torch.from_numpy(synth.gauss_priors(T, h, w)))
+        o.append(torch.from_numpy(synth.ob_priors(T, h, w, seed=seed + c)))
+    return torch.stack(xs), [torch.stack(g), torch.stack(o)]
+
+
+def run_clips_case(ref_model, name, H, W, T, C, seed=0, calls=1, map_stride=1, state_stride=47):
+    """Batched-clips semantics of BASELINE configs[2]-[4]: C independent reference
+    calls `forward(x_c [T,3,H,W], cb_c, [state_c])` with time_dims=T, each clip carrying its own state
+    over `calls` successive calls (Demo_Test.py:75-86).  Stored: the maps (every `map_stride`-th value of
+    the flattened [C,T,1,h,w] tensor + the full maps of clip 0), strided state samples, float64 sums."""
+    h, w = H // 8, W // 8
+    model = ref_model.UAVSal(cnn_type="mobilenet_v2", time_dims=T, num_stblock=2, bias_type=[1, 1, 1],
+                             iosize=[H, W, h, w], planes=256, pre_model_path="")
+    synth.load_synth_weights(model, seed)
+    model.eval()
+    rec = {"H": H, "W": W, "T": T, "C": C, "seed": seed, "calls": calls, "map_stride": map_stride,
+           "state_stride": state_stride,
+           "weights_sha256": np.frombuffer(bytes.fromhex(weights_digest(model)), dtype=np.uint8)}
+    states = [torch.zeros(1, 256, h, w) for _ in range(C)]
+    with torch.no_grad():
+        for call in range(calls):
+            x, cb = clip_inputs(C, T, H, W, seed, t0=call * T)
+            outs = []
+            for c in range(C):
+                out, st = model(x[c], [cb[0][c], cb[1][c]], [states[c]])
+                states[c] = st[0].detach()
+                outs.append(out)
+                print("  %s call %d clip %d done" % (name, call, c), flush=True)
+            out = torch.stack(outs)                       # [C,T,1,h,w]
+            st = torch.cat(states, 0)                     # [C,256,h,w]
+            sfx = "" if call == 0 else f"_call{call}"
+            rec["out" + sfx] = sub(out, map_stride)
+            rec["out_clip0" + sfx] = out[0].numpy().astype(np.float32)
+            rec["out_sum" + sfx] = np.float64(out.double().sum().item())
+            rec["state" + sfx] = sub(st, state_stride)
+            rec["state_sum" + sfx] = np.float64(st.double().sum().item())
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **rec)
+    print("%-28s out %.5f..%.5f -> %s (%.0f KB)" % (name, rec["out"].min(), rec["out"].max(),
+                                                    os.path.basename(path), os.path.getsize(path) / 1024))
+
+
 def run_convlstm(ref_rnn, seed=0):
     """One ConvLSTMCell step from the reference's model_convlstm.py (imports as-is)."""
     hid, h, w = 32, 9, 11
@@ -148,11 +197,20 @@ def run_convlstm(ref_rnn, seed=0):
 
 
 def main():
+    only = sys.argv[1:]
     if not os.path.isdir(REF):
         raise SystemExit("reference not present: goldens can only be generated in the authoring container")
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     ref_model, ref_rnn = import_reference()
+    if not only or "clips" in only:
+        # BASELINE configs[2]/[3]: 360x640, 8 independent clips x 8 frames (one GPU's share of configs[3])
+        run_clips_case(ref_model, "clips_360x640_C8_T8", 360, 640, 8, 8)
+        # BASELINE configs[4]: 720x1280, 4 clips x 16 frames, two successive calls with carried state
+        run_clips_case(ref_model, "clips_720x1280_C4_T16_two_calls", 720, 1280, 16, 4, calls=2, map_stride=5,
+                       state_stride=211)
+    if only and "base" not in only:
+        return
     run_case(ref_model, "e2e_96x160_T4", 96, 160, 4)
     run_case(ref_model, "e2e_96x160_B4T5", 96, 160, 5, B=4, tap_stride=61)             # Demo_Test.py default chunking
     run_case(ref_model, "e2e_96x160_T4_two_calls", 96, 160, 4, calls=2)  # carried state

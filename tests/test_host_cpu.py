@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert declared == bound, (declared ^ bound)
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.uavsal_abi_version() == 7
+    assert lib.uavsal_abi_version() == 8
     assert b"gfx950" in lib.uavsal_build_info()
 
 
@@ -56,6 +56,12 @@ def test_argument_validation_without_gpu(lib):
     p = lib.uavsal_plan_create()
     assert lib.uavsal_plan_size(p) == 0
     assert lib.uavsal_plan_graph_launch(p, None) == -4             # no graph built yet
+    assert lib.uavsal_plan_status(p, 1) == 0                       # nothing was run
+    g = L.GuardDesc()
+    assert lib.uavsal_guard(C.byref(g), None) == -1                # no error word
+    c = L.CopyDesc()
+    c.inp, c.out, c.rows, c.row_floats, c.in_pitch, c.out_pitch = 16, 16, 2, 6, 8, 8
+    assert lib.uavsal_copy_rows(C.byref(c), None) == -2            # rows must be float4 multiples
     lib.uavsal_plan_destroy(p)
 
 
@@ -179,7 +185,16 @@ def _worker(rank, world, port, q):
     x = torch.from_numpy(synth.normalize_frames(synth.synth_frames_u8(C * T, H, W))).view(C, T, 3, H, W)
     cb = [torch.from_numpy(synth.gauss_priors(C * T, 9, 13)).view(C, T, 8, 9, 13),
           torch.from_numpy(synth.ob_priors(C * T, 9, 13)).view(C, T, 20, 9, 13)]
-    out, st = forward_clips_sharded(model, x, cb)
+    out, st = forward_clips_sharded(model, x, cb)                       # full batch, sliced per rank
+    # production form: the rank holds only its own shard of the frames
+    out_l, st_l = forward_clips_sharded(model, x[rank:rank + 1], [cb[0][rank:rank + 1], cb[1][rank:rank + 1]],
+                                        total_clips=C)
+    assert torch.equal(out, out_l) and torch.equal(st, st_l)
+    try:
+        forward_clips_sharded(model, x, cb, total_clips=C)               # a full batch is not a shard
+        raise AssertionError("shard size was not checked")
+    except RuntimeError:
+        pass
     q.put((rank, out.numpy(), st.numpy()))
     dist.barrier()
     dist.destroy_process_group()
@@ -256,6 +271,10 @@ def test_reference_style_whole_model_pickle_loads_through_the_shim(tmp_path):
     load_reference_checkpoint(dst, path)
     for k, v in src.state_dict().items():
         assert torch.equal(v, dst.state_dict()[k]), k
+    # the constructor's pre_model_path (reference model.py:338-339) goes through the same shim
+    dst2 = UAVSal(time_dims=3, pre_model_path=path)
+    for k, v in src.state_dict().items():
+        assert torch.equal(v, dst2.state_dict()[k]), k
 
 
 def test_mat_reader_and_priors(golden_dir):

@@ -61,6 +61,22 @@ def test_oracle_matches_reference_golden(name, golden_dir):
                 np.testing.assert_allclose(_sub(taps[k], int(g["tap_stride"])), g["tap_" + k], rtol=0, atol=5e-5)
 
 
+def test_oracle_clips_match_reference_golden(golden_dir):
+    """Batched-clips goldens (BASELINE configs[2]/[3] shape: 8 independent reference calls at 360x640): the
+    oracle's forward_clips on one of the clips (CPU time) against the reference's maps and state digest."""
+    g = np.load(os.path.join(golden_dir, "clips_360x640_C8_T8.npz"))
+    H, W, T, C, seed = int(g["H"]), int(g["W"]), int(g["T"]), int(g["C"]), int(g["seed"])
+    assert int(g["map_stride"]) == 1
+    c = 5
+    h, w = H // 8, W // 8
+    x = torch.from_numpy(synth.normalize_frames(synth.synth_frames_u8(T, H, W, seed + c)))[None]
+    cb = [torch.from_numpy(synth.gauss_priors(T, h, w))[None], torch.from_numpy(synth.ob_priors(T, h, w, seed=seed + c))[None]]
+    out, st = R.build_oracle(time_dims=T, seed=seed).forward_clips(x, cb)
+    ref = g["out"].reshape(C, T, 1, h, w)[c]
+    np.testing.assert_allclose(out[0].numpy(), ref, rtol=0, atol=2e-6)
+    assert np.array_equal(g["out"].reshape(C, T, 1, h, w)[0], g["out_clip0"])
+
+
 def test_state_dict_schema_known_answer():
     """Reference known answer: 51.59 MB params+buffers (Tools/Getmodelsize_demo.py:93);
     SURVEY.md 8(b): 685 entries, 13 407 338 parameters."""
