@@ -585,7 +585,8 @@ class Engine:
                 self.c_view = c0.t.view(self.n_seq, h, w, 256).permute(0, 3, 1, 2) if lstm else None
             else:
                 bufs.append((self.state_out.data_ptr(), self.state_out.numel()))
-                r = self.lib.uavsal_plan_add_guard(self.plan, bufs[0][0], bufs[0][1], bufs[1][0], bufs[1][1], bufs[2][0], bufs[2][1])
+                bufs.append((self.cstate_out.data_ptr(), self.cstate_out.numel()) if lstm else (None, 0))
+            r = self.lib.uavsal_plan_add_guard(self.plan, bufs[0][0], bufs[0][1], bufs[1][0], bufs[1][1], bufs[2][0], bufs[2][1])
             if r < 0:
                 L.check(r, "plan_add_guard")
         self._mark("decoder", s0)
