@@ -52,16 +52,55 @@ def kernel_symbol(prec, tile, taps, streamk=0):
     return "conv_gemm_kernel<%s>" % (H16_INST[tile] % (PREC_ID[prec], taps))
 
 
+TRAFFIC_FILE = os.path.join("profiles", "r2_hbm_traffic_f32_c1.json")
+
+
 def measured_traffic(symbol, C, T, H, W, prec):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950
-    note, + WRITE_SIZE; profiles/r1_hbm_traffic_f32_c1_v3.json, collected for configs[1] only)."""
-    if (C, T, H, W, prec) != (1, 8, 360, 640, "f32"):
-        return None
-    path = os.path.join(ROOT, "profiles", "r1_hbm_traffic_f32_c1_v3.json")
-    if not os.path.exists(path):
-        return None
-    rec = json.load(open(path)).get(symbol)
-    return None if rec is None else round(rec["hbm_mb_per_launch"] * 1e6)
+    """(HBM bytes per launch, source) from the committed rocprofv3 PMC passes: two separate `--pmc` runs of
+    this bench command (FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md, + WRITE_SIZE),
+    summarised by tools/traffic_report.py.  The counters cannot be collected by the run that prints the
+    line (rocprofv3 wraps the process), so the file carries a stamp -- ABI version and a hash of the kernel
+    sources it was collected on -- and the figure is withheld (null) when the stamp does not match this
+    build or the workload is not the one it was collected for."""
+    src = {"file": TRAFFIC_FILE, "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), FETCH x2 (gfx950)"}
+    path = os.path.join(ROOT, TRAFFIC_FILE)
+    if (C, T, H, W, prec) != (1, 8, 360, 640, "f32") or not os.path.exists(path):
+        src["status"] = "no PMC collection for this workload"
+        return None, src
+    blob = json.load(open(path))
+    stamp = blob.get("__stamp__", {})
+    src["stamp"] = stamp
+    if stamp.get("kernel_sources_sha16") != kernel_sources_sha16():
+        src["status"] = "stale: kernel sources changed since the PMC passes"
+        return None, src
+    rec = blob.get(symbol)
+    if rec is None:
+        src["status"] = "kernel not in the PMC summary"
+        return None, src
+    src["status"] = "ok"
+    return round(rec["hbm_mb_per_launch"] * 1e6), src
+
+
+def kernel_sources_sha16():
+    import hashlib
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "iip_uavsal_saliency_amd", "csrc")
+    for name in sorted(os.listdir(base)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(base, name), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "uavsal_hip.h"), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def log(msg):
@@ -103,12 +142,7 @@ def kernel_rooflines(eng, prec, iters=5):
             if m.get("fused_dw"):
                 key = "conv_gemm_kernel<%s, true>" % (H16_INST[m["tile"]] % (PREC_ID[prec], 1))
         elif m["kind"] == "dw":
-            if m.get("dil", 1) != 1:
-                key = "dw3x3_dilated_kernel"
-            elif m.get("stride", 1) != 1:
-                key = "dw3x3_kernel<2, 2, 2>"
-            else:      # small maps take 2x2 patches (dw_conv.hip: fewer than 512 workgroups of 4x4 patches)
-                key = "dw3x3_kernel<1, 2, 2>" if (m.get("patches44", 1 << 30) + 255) // 256 < 512 else "dw3x3_kernel<1, 4, 4>"
+            key = m["kernel"]                  # uavsal_dw_variant: the instance the library launches
         else:
             key = m["kind"]
         if os.environ.get("UAVSAL_BENCH_OPS"):
@@ -139,6 +173,26 @@ def roofline_obj(name, g, prec):
             "alg_mb_per_launch": round(g["bytes"] / g["launches"] / 1e6, 3)}
 
 
+def depthwise_family(groups):
+    """every depthwise layer of the forward (34 at 360x640), algorithmic bytes
+    N*C*(HiWi+HoWo)*4 + 44*C summed over the layers / their summed kernel time, against the HBM peak.
+    The per-instance split is kept beside the family figure."""
+    dw = {k: g for k, g in groups.items() if g["kind"] == "dw"}
+    if not dw:
+        return None
+    byts = sum(g["bytes"] for g in dw.values())
+    ms = sum(g["ms"] for g in dw.values())
+    fam = {"kernel": "depthwise 3x3 family (all dw layers of the forward)", "bound": "hbm",
+           "achieved": round(byts / ms / 1e6, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+           "frac": round(byts / ms / 1e6 / PEAK_HBM_GBS, 4), "traffic": None,
+           "launches_per_step": sum(g["launches"] for g in dw.values()),
+           "alg_mb_per_step": round(byts / 1e6, 3), "kernel_ms_per_step": round(ms, 4), "instances": {}}
+    for k, g in sorted(dw.items(), key=lambda kv: -kv[1]["ms"]):
+        fam["instances"][k] = {"launches": g["launches"], "ms": round(g["ms"], 4), "alg_mb": round(g["bytes"] / 1e6, 3),
+                               "frac": round(g["bytes"] / g["ms"] / 1e6 / PEAK_HBM_GBS, 4)}
+    return fam
+
+
 def timed_steps(fn, steps, warmup, distributed, device):
     for _ in range(warmup):
         fn()
@@ -164,7 +218,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--clips", type=int, default=1, help="clips per GPU (BASELINE configs[1]: 1)")
+    ap.add_argument("--clips", type=int, default=0, help="clips per GPU; default 1 on one GPU (BASELINE configs[1]) "
+                    "and 8 per GPU when --gpus > 1 (configs[3]: 8 clips/GPU); pass --clips 8 --gpus 1 for the "
+                    "matching single-GPU point of a scaling curve")
+    ap.add_argument("--windows", type=int, default=3, help="timed windows of --steps steps each; the median is reported")
     ap.add_argument("--frames", type=int, default=8)
     ap.add_argument("--height", type=int, default=360)
     ap.add_argument("--width", type=int, default=640)
@@ -196,6 +253,8 @@ def main():
     from iip_uavsal_saliency_amd import UAVSal, synth
     from iip_uavsal_saliency_amd.parallel import ClipShard, gather_maps
 
+    if args.clips <= 0:
+        args.clips = 8 if world > 1 else 1
     C, T, H, W = args.clips, args.frames, args.height, args.width
     h, w = H // 8, W // 8
     shard = ClipShard(total_clips=C * world, world_size=world, rank=rank)
@@ -221,14 +280,20 @@ def main():
         last["out"], last["state"] = out, st
 
     log("model + inputs ready; timing %d steps" % args.steps)
-    dt = timed_steps(step, args.steps, args.warmup, distributed, device)
-    log("timed region done: %.3f ms/step" % (dt / args.steps * 1e3))
+    # every window is exactly --steps steps between barrier + synchronize on both sides (max over ranks);
+    # the median window is the reported one, all of them are listed
+    wins = [timed_steps(step, args.steps, args.warmup if i == 0 else 0, distributed, device)
+            for i in range(max(1, args.windows))]
+    dt = sorted(wins)[len(wins) // 2]
+    log("timed region done: %.3f ms/step (windows: %s)" % (dt / args.steps * 1e3,
+                                                           ", ".join("%.3f" % (w / args.steps * 1e3) for w in wins)))
     frames = C * T * world * args.steps
     fps = frames / dt
     result = {
         "metric": "saliency frames/sec at 360x640" if (H, W) == (360, 640) else "saliency frames/sec at %dx%d" % (H, W),
         "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "windows_ms_per_step": [round(w / args.steps * 1e3, 4) for w in wins],
         "vs_baseline": None, "dtype": DTYPE_NAME[args.prec], "data": "synthetic",
         "config": {"workload": "%dx%d batch=%d clip(s)/GPU seq=%d, UAVSal.forward_clips, prec=%s, %s" % (
             H, W, C, T, args.prec, "hipGraph replay" if args.graph else "launch loop"),
@@ -246,12 +311,14 @@ def main():
             dom = max(groups.items(), key=lambda kv: kv[1]["ms"])
             result["roofline"] = roofline_obj(dom[0], dom[1], args.prec)
             result["roofline"]["share_of_kernel_time"] = round(dom[1]["ms"] / tot, 3)
-            result["roofline"]["traffic"] = measured_traffic(dom[0], C, T, H, W, args.prec)
-            dwk = "dw3x3_kernel<1, 4, 4>"
-            if dwk in groups:
-                result["roofline_dw"] = roofline_obj(dwk, groups[dwk], args.prec)
-                result["roofline_dw"]["share_of_kernel_time"] = round(groups[dwk]["ms"] / tot, 3)
-                result["roofline_dw"]["traffic"] = measured_traffic(dwk, C, T, H, W, args.prec)
+            result["roofline"]["traffic"], result["roofline"]["traffic_source"] = measured_traffic(dom[0], C, T, H, W, args.prec)
+            fam = depthwise_family(groups)
+            if fam:
+                fam["share_of_kernel_time"] = round(fam["kernel_ms_per_step"] / tot, 3)
+                big = "dw3x3_kernel<1, 4, 4>"
+                if big in fam["instances"]:
+                    fam["instances"][big]["traffic"], _ = measured_traffic(big, C, T, H, W, args.prec)
+                result["roofline_dw"] = fam
             result["kernel_time_ms"] = {k: round(v["ms"], 4) for k, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])}
             result["stage_time_ms"] = {k: round(eng.time_ops(a, b, 5), 4) for k, (a, b) in eng.stage_ranges.items()}
         if not args.no_cpu_baseline:
@@ -269,12 +336,34 @@ def main():
                 best = min(best, time.perf_counter() - t0)
                 log("cpu baseline pass: %.2f s" % best)
             result["cpu_baseline"] = {"value": round(T / best, 3), "unit": "frames/s", "cores": torch.get_num_threads(),
-                                      "kind": "port", "sample": "1 clip x %d frames at %dx%d, best of 3 after 1 warm-up, "
+                                      "kind": "port", "cpu_model": cpu_model(),
+                                      "sample": "1 clip x %d frames at %dx%d, best of 3 after 1 warm-up, "
                                       "torch-CPU fp32 oracle (oracle/uavsal_ref.py)" % (T, H, W)}
+            torch.set_num_threads(1)                          # also the 1-thread figure
+            t0 = time.perf_counter()
+            oracle.forward_clips(xc, cbc)
+            one = time.perf_counter() - t0
+            log("cpu baseline, 1 thread: %.2f s" % one)
+            result["cpu_baseline"]["value_1_thread"] = round(T / one, 3)
+            result["cpu_baseline"]["sample_1_thread"] = "the same clip once on 1 thread (%.1f s)" % one
+            torch.set_num_threads(cores)
             err = (last["out"][:1].cpu() - ref_out).abs().max().item()
             serr = (last["state"][:1].cpu() - ref_state).abs().max().item()
             result["parity"] = {"max_abs_map_vs_cpu_ref": float("%.3e" % err), "max_abs_state_vs_cpu_ref": float("%.3e" % serr),
                                 "tolerance": 1e-3}
+        if not args.no_extra and C != 8:
+            # the single-GPU point of the multi-GPU curve: `--gpus N` (N > 1) runs configs[3]'s 8 clips per GPU,
+            # so the matching 1-GPU figure (same per-GPU workload, same precision) is measured here
+            log("scaling reference: 8 clips on this GPU, %s" % args.prec)
+            x8, cb8 = make_clips(8, T, H, W)
+            x8 = x8.to(device)
+            cb8 = [cb8[0].to(device), cb8[1].to(device)]
+            ks = max(3, args.steps // 4)
+            dt8 = timed_steps(lambda: model.forward_clips(x8, cb8, None), ks, 1, False, device)
+            result["scaling_reference"] = {"workload": "%dx%d batch=8 clip(s)/GPU seq=%d, prec=%s (what --gpus N>1 runs per GPU)" % (H, W, T, args.prec),
+                                           "value": round(8 * T * ks / dt8, 2), "unit": "frames/s", "n_gpus": 1, "steps": ks}
+            del x8, cb8
+            model.invalidate_engines()
         if not args.no_extra and args.prec == "f32":
             # the same workload, and BASELINE.json's configs[2] shape, in the split-fp16 precision
             # (fp32-class: held to the 5e-4 parity bound by tests/test_hip_e2e.py); informative only

@@ -21,6 +21,8 @@ _ERR = {-1: "UAVSAL_EINVAL (null pointer / non-positive size)",
         -4: "UAVSAL_ESTATE (plan used in the wrong state)",
         -5: "UAVSAL_EDEVICE (a kernel reported a device-side error; the run's outputs are invalid)"}
 ERR_STREAMK = 1
+DW_KERNEL = {1: "dw3x3_kernel<1, 4, 4>", 2: "dw3x3_kernel<1, 2, 2>", 3: "dw3x3_kernel<2, 2, 2>", 4: "dw3x3_dilated_kernel",
+             16: "dw3x3_map_lds_kernel<16>", 32: "dw3x3_map_lds_kernel<32>", 64: "dw3x3_map_lds_kernel<64>"}
 
 _f = C.c_void_p   # device pointers travel as integers
 
@@ -99,6 +101,7 @@ SYMBOLS = [
     ("uavsal_streamk_workspace_bytes", C.c_longlong, []),
     ("uavsal_conv_streamk_grid", C.c_int, [C.POINTER(ConvDesc)]),
     ("uavsal_dw3x3", C.c_int, [C.POINTER(DwDesc), C.c_void_p]),
+    ("uavsal_dw_variant", C.c_int, [C.POINTER(DwDesc)]),
     ("uavsal_stem_conv", C.c_int, [C.POINTER(StemDesc), C.c_void_p]),
     ("uavsal_bilinear_ac", C.c_int, [C.POINTER(BilinearDesc), C.c_void_p]),
     ("uavsal_tdiff", C.c_int, [C.POINTER(TdiffDesc), C.c_void_p]),

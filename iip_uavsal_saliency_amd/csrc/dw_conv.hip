@@ -133,6 +133,102 @@ __global__ __launch_bounds__(256) void dw3x3_dilated_kernel(const DwK p) {
     *reinterpret_cast<f32x4*>(p.out + (((size_t)n * p.Ho + oy) * p.Wo + ox) * p.ldo + c) = v;
 }
 
+// Small maps (the 1/32- and 1/16-scale levels: 12x20, 23x40 at 360x640): one workgroup stages the WHOLE
+// map of one image for a slab of CB channels in LDS (<= 64 KB) with coalesced 16-byte loads, then every
+// output reads its nine taps from LDS -- each input byte is fetched from L2/HBM exactly once whatever the
+// dilation (the per-tap global loads of the generic dilated kernel made d=6 -- all nine taps inside the map
+// -- twice as slow as d=18).  Stride 1, any dilation.  Thread i handles float4 item i of the slab
+// (pixel = i / (CB/4), channel quad = i % (CB/4)); 256 % (CB/4) == 0, so a thread keeps one channel quad
+// and its taps / BN constants stay in registers.
+template <int CB>
+__global__ __launch_bounds__(256) void dw3x3_map_lds_kernel(const DwK p) {
+    extern __shared__ __attribute__((aligned(16))) float smap[];
+    constexpr int Q = CB / 4;
+    const int slabs = (p.C4 * 4 + CB - 1) / CB;
+    const int n = blockIdx.x / slabs, c0 = (blockIdx.x - n * slabs) * CB;
+    const int q = threadIdx.x % Q;
+    const int c = c0 + q * 4;
+    const bool cok = c < p.C4 * 4;                 // last slab may be narrower
+    const int HW = p.H * p.W;
+    const float* inb = p.in + (size_t)n * HW * p.ldi + c;
+    f32x4* sm = reinterpret_cast<f32x4*>(smap);
+    for (int i = threadIdx.x; i < HW * Q; i += 256) {
+        const int pix = i / Q;
+        sm[i] = cok ? ld4(inb + (size_t)pix * p.ldi) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    f32x4 wt[9];
+    const int cc = cok ? c : 0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wt[k] = ld4(p.w9c + (size_t)k * (p.C4 * 4) + cc);
+    const f32x4 sc = ld4(p.scale + cc), bi = ld4(p.bias + cc);
+    __syncthreads();
+    if (!cok) return;
+    float* outb = p.out + (size_t)n * HW * p.ldo + c;
+    for (int i = threadIdx.x; i < HW * Q; i += 256) {
+        const int pix = i / Q;
+        const int oy = pix / p.W, ox = pix - oy * p.W;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy + (ky - 1) * p.dil;
+            if (iy < 0 || iy >= p.H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox + (kx - 1) * p.dil;
+                if (ix < 0 || ix >= p.W) continue;
+                acc += sm[(iy * p.W + ix) * Q + q] * wt[ky * 3 + kx];
+            }
+        }
+        f32x4 v = acc * sc + bi;
+        if (p.act == UAVSAL_ACT_RELU6) {
+            v.x = fminf(fmaxf(v.x, 0.f), 6.f); v.y = fminf(fmaxf(v.y, 0.f), 6.f);
+            v.z = fminf(fmaxf(v.z, 0.f), 6.f); v.w = fminf(fmaxf(v.w, 0.f), 6.f);
+        }
+        *reinterpret_cast<f32x4*>(outb + (size_t)pix * p.ldo) = v;
+    }
+}
+
+template <int CB>
+int launch_map_lds(DwK k, hipStream_t s) {
+    const int slabs = (k.C4 * 4 + CB - 1) / CB;
+    const size_t smem = (size_t)k.H * k.W * CB * 4;
+    hipLaunchKernelGGL((dw3x3_map_lds_kernel<CB>), dim3((unsigned)(k.n_img * slabs)), dim3(256), smem, s, k);
+    return uavsal_launch_status();
+}
+
+// channel slab width for the whole-map kernel, 0 = the map does not fit 64 KB of LDS at 16 channels
+static inline int map_lds_slab(const DwK& k) {
+    const long long px = (long long)k.H * k.W;
+    if (px * 16 * 4 > 65536) return 0;
+    const int cands[3] = {64, 32, 16};
+    for (int i = 0; i < 3; ++i) {      // widest slab that fits and still gives every CU a workgroup
+        const int cb = cands[i];
+        if (px * cb * 4 <= 65536 && (long long)k.n_img * ((k.C4 * 4 + cb - 1) / cb) >= 256) return cb;
+    }
+    return 16;
+}
+
+// which kernel a descriptor gets: 1 = dw3x3_kernel<1,4,4>, 2 = <1,2,2>, 3 = <2,2,2>, 4 = dw3x3_dilated_kernel,
+// 16 / 32 / 64 = dw3x3_map_lds_kernel<CB>
+static int dw_variant(const DwK& k, int stride, int dilation) {
+    // Measured at 8 x 12x20 x 1920 (profiles/r2_dw_small_maps.md): the whole-map LDS kernel wins only while most
+    // taps fall inside the map (d=6: 10.9 vs 15.1 us); d=12/18 (centre row only) and dilation 1 (2x2 patches
+    // already fetch every input 2.25x, from L1/L2) are faster on the direct kernels (8.7 / 7.7 us vs 9.3 / 9.4;
+    // 7.3 vs 18 us at 23x40).
+    if (stride == 1 && dilation != 1 && 2 * dilation <= (k.H < k.W ? k.H : k.W)) {
+        const int cb = map_lds_slab(k);
+        if (cb) return cb;
+    }
+    if (dilation != 1) return 4;
+    if (stride == 1) {
+        // 4x4 patches need ~2x fewer loads per output, but on the 12x20 / 23x40 maps they leave most of the
+        // chip without a workgroup: below 2 workgroups per CU's worth of patches use 2x2 ones (4x the threads)
+        const long long wg44 = ((long long)k.n_img * ((k.Ho + 3) / 4) * ((k.Wo + 3) / 4) * k.C4 + 255) / 256;
+        return wg44 < 512 ? 2 : 1;
+    }
+    return 3;
+}
+
 template <int S, int TY, int TX>
 int launch_dw(DwK k, hipStream_t s) {
     k.tiles_x = (k.Wo + TX - 1) / TX;
@@ -162,20 +258,30 @@ extern "C" int uavsal_dw3x3(const uavsal_dw_desc* d, uavsal_stream_t stream) {
     k.C4 = d->C / 4; k.dil = d->dilation; k.act = d->act; k.n_img = d->n_img;
     k.tiles_x = k.tiles_y = 0; k.total = 0; k.nblk = 0;
     hipStream_t s = (hipStream_t)stream;
-    if (d->dilation != 1) {
-        k.total = (long long)k.n_img * k.Ho * k.Wo * k.C4;
-        const long long nblk = (k.total + 255) / 256;
-        if (nblk > 0x7fffffffLL) return UAVSAL_ESHAPE;
-        k.nblk = (int)nblk;
-        hipLaunchKernelGGL(dw3x3_dilated_kernel, dim3(k.nblk), dim3(256), 0, s, k);
-        return uavsal_launch_status();
+    const int v = dw_variant(k, d->stride, d->dilation);
+    switch (v) {
+        case 64: return launch_map_lds<64>(k, s);
+        case 32: return launch_map_lds<32>(k, s);
+        case 16: return launch_map_lds<16>(k, s);
+        case 4: {
+            k.total = (long long)k.n_img * k.Ho * k.Wo * k.C4;
+            const long long nblk = (k.total + 255) / 256;
+            if (nblk > 0x7fffffffLL) return UAVSAL_ESHAPE;
+            k.nblk = (int)nblk;
+            hipLaunchKernelGGL(dw3x3_dilated_kernel, dim3(k.nblk), dim3(256), 0, s, k);
+            return uavsal_launch_status();
+        }
+        case 1: return launch_dw<1, 4, 4>(k, s);
+        case 2: return launch_dw<1, 2, 2>(k, s);
+        default: return launch_dw<2, 2, 2>(k, s);
     }
-    if (d->stride == 1) {
-        // 4x4 patches need ~2x fewer loads per output, but on the 12x20 / 23x40 maps they leave most of the
-        // chip without a workgroup: below 2 workgroups per CU's worth of patches use 2x2 ones (4x the threads)
-        const long long wg44 = ((long long)k.n_img * ((k.Ho + 3) / 4) * ((k.Wo + 3) / 4) * k.C4 + 255) / 256;
-        if (wg44 < 512) return launch_dw<1, 2, 2>(k, s);
-        return launch_dw<1, 4, 4>(k, s);
-    }
-    return launch_dw<2, 2, 2>(k, s);
+}
+
+extern "C" int uavsal_dw_variant(const uavsal_dw_desc* d) {
+    if (!d || d->n_img <= 0 || d->H <= 0 || d->W <= 0 || d->C <= 0 || (d->C & 3)) return UAVSAL_EINVAL;
+    if ((d->stride != 1 && d->stride != 2) || d->dilation < 1 || (d->stride == 2 && d->dilation != 1)) return UAVSAL_ESHAPE;
+    DwK k;
+    k.H = d->H; k.W = d->W; k.Ho = (d->H - 1) / d->stride + 1; k.Wo = (d->W - 1) / d->stride + 1;
+    k.C4 = d->C / 4; k.n_img = d->n_img;
+    return dw_variant(k, d->stride, d->dilation);
 }

@@ -283,6 +283,7 @@ class Engine:
         d.out, d.ldo = out.ptr, out.ld
         d.n_img, d.H, d.W, d.C = a.n, a.h, a.w, c
         d.stride, d.dilation, d.act = stride, dilation, L.ACT_RELU6
+        self.ops_meta[-1]["kernel"] = L.DW_KERNEL.get(int(self.lib.uavsal_dw_variant(C.byref(d))), "dw3x3")
         self._add(self.lib.uavsal_plan_add_dw, d, "plan_add_dw(%s)" % name)
 
     def bilinear(self, name, a: V, out: V, src_mod=None, src_div=1):

@@ -169,6 +169,10 @@ typedef struct uavsal_dw_desc {
 } uavsal_dw_desc;
 
 int uavsal_dw3x3(const uavsal_dw_desc* d, uavsal_stream_t stream);
+/* kernel instance `uavsal_dw3x3` will use for this descriptor; no launch.  1: dw3x3_kernel<1,4,4> (4x4 output
+ * patch per thread), 2: <1,2,2>, 3: <2,2,2> (stride 2), 4: dw3x3_dilated_kernel (one pixel per thread),
+ * 16 / 32 / 64: dw3x3_map_lds_kernel<CB> (whole map of a CB-channel slab staged in LDS; small maps, any dilation) */
+int uavsal_dw_variant(const uavsal_dw_desc* d);
 
 /*
  * Stem: dense 3x3 stride-2 pad-1 convolution 3 -> 32 + BatchNorm + ReLU6 reading the

@@ -253,6 +253,9 @@ DW_CASES = [
     (2, 9, 13, 48, 1, 1), (1, 12, 20, 120, 1, 1), (2, 45, 80, 1536, 1, 1), (1, 23, 41, 96, 2, 1),
     (2, 45, 80, 1536, 2, 1), (1, 180, 320, 32, 1, 1), (2, 12, 20, 1920, 1, 6), (2, 12, 20, 1920, 1, 12),
     (2, 12, 20, 1920, 1, 18), (1, 5, 3, 144, 2, 1), (1, 1, 1, 64, 1, 1), (1, 2, 2, 64, 2, 1),
+    # whole-map LDS kernel: last channel slab narrower than the slab, 8 images (slab 32), odd map, and a map
+    # too large for LDS (generic dilated kernel)
+    (1, 12, 20, 120, 1, 2), (8, 12, 20, 960, 1, 6), (3, 23, 40, 96, 1, 3), (1, 45, 80, 64, 1, 2), (2, 7, 5, 20, 1, 4),
 ]
 
 
