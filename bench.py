@@ -46,7 +46,12 @@ H16_INST = {1: "%d, 2, 2, 2, 2, %d", 2: "%d, 4, 1, 1, 2, %d", 3: "%d, 4, 1, 1, 1
             5: "%d, 2, 4, 2, 2, %d", 6: "%d, 2, 4, 4, 2, %d"}
 
 
-def kernel_symbol(prec, tile, taps, streamk=0):
+H16_DMA_INST = {1: "2, 2, 2, 2, %d, 2", 5: "2, 4, 2, 2, %d, 3", 6: "2, 4, 4, 2, %d, 2"}    # pre-split LDS-DMA path
+
+
+def kernel_symbol(prec, tile, taps, streamk=0, split=False):
+    if split:
+        return "conv_gemm_h16_dma_kernel<%s>" % (H16_DMA_INST[tile] % taps)
     if prec == "f32":
         return "conv_gemm_f32_dma_kernel<%s>" % ((F32_SK_INST if streamk else F32_INST)[tile] % taps)
     return "conv_gemm_kernel<%s>" % (H16_INST[tile] % (PREC_ID[prec], taps))
@@ -138,7 +143,7 @@ def kernel_rooflines(eng, prec, iters=5):
     for i, m in enumerate(eng.ops_meta):
         ms = eng.time_ops(i, i + 1, iters)
         if m["kind"].startswith("conv"):
-            key = kernel_symbol(prec, m["tile"], 9 if m["kind"] == "conv3" else 1, m.get("streamk", 0))
+            key = kernel_symbol(prec, m["tile"], 9 if m["kind"] == "conv3" else 1, m.get("streamk", 0), m.get("split", False))
             if m.get("fused_dw"):
                 key = "conv_gemm_kernel<%s, true>" % (H16_INST[m["tile"]] % (PREC_ID[prec], 1))
         elif m["kind"] == "dw":
@@ -231,6 +236,8 @@ def main():
     ap.add_argument("--lanes", type=int, default=1, help="run independent branches on parallel streams / graph branches")
     ap.add_argument("--fuse-dw", type=int, default=-1, help="-1 engine default, 0/1 force the fused depthwise->projection GEMM")
     ap.add_argument("--stream-k", type=int, default=1, help="fp32 GEMMs: stream-K when whole tiles would idle CUs")
+    ap.add_argument("--presplit", type=int, default=1, help="f16x3: producers also write split shadows and the eligible GEMMs "
+                    "stage both operands by LDS-DMA (0: every GEMM re-splits its fp32 input while staging)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
@@ -265,6 +272,7 @@ def main():
     model.fuse_dw = None if args.fuse_dw < 0 else bool(args.fuse_dw)
     model.use_lanes = bool(args.lanes)
     model.stream_k = bool(args.stream_k)
+    model.presplit = bool(args.presplit)
 
     x_cpu, cb_cpu = make_clips(C, T, H, W, seed=shard.first)       # this rank's clips
     x = x_cpu.to(device)

@@ -40,6 +40,8 @@ class ConvDesc(C.Structure):
                 ("dw_w9c", _f), ("dw_scale", _f), ("dw_bias", _f),
                 ("dw_stride", C.c_int32), ("dw_Hin", C.c_int32), ("dw_Win", C.c_int32),
                 ("sk_ws", _f), ("sk_ws_bytes", C.c_int64),
+                ("a_split", _f), ("ldas", C.c_int32),
+                ("out_split", _f), ("ldos", C.c_int32),
                 ("err", _f), ("sk_spin_limit", C.c_int32), ("sk_debug_drop", C.c_int32)]
 
 
@@ -47,7 +49,8 @@ class DwDesc(C.Structure):
     _fields_ = [("inp", _f), ("ldi", C.c_int32), ("w9c", _f), ("scale", _f), ("bias", _f),
                 ("out", _f), ("ldo", C.c_int32),
                 ("n_img", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32),
-                ("stride", C.c_int32), ("dilation", C.c_int32), ("act", C.c_int32)]
+                ("stride", C.c_int32), ("dilation", C.c_int32), ("act", C.c_int32),
+                ("out_split", _f), ("ldos", C.c_int32)]
 
 
 class StemDesc(C.Structure):
@@ -60,7 +63,8 @@ class StemDesc(C.Structure):
 class BilinearDesc(C.Structure):
     _fields_ = [("inp", _f), ("ldi", C.c_int32), ("Hi", C.c_int32), ("Wi", C.c_int32),
                 ("out", _f), ("ldo", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32),
-                ("n_out", C.c_int32), ("C", C.c_int32), ("src_mod", C.c_int32), ("src_div", C.c_int32)]
+                ("n_out", C.c_int32), ("C", C.c_int32), ("src_mod", C.c_int32), ("src_div", C.c_int32),
+                ("out_split", _f), ("ldos", C.c_int32)]
 
 
 class TdiffDesc(C.Structure):
@@ -98,6 +102,7 @@ DESC_TYPES = [ConvDesc, DwDesc, StemDesc, BilinearDesc, TdiffDesc, TsumDesc, Lay
 SYMBOLS = [
     ("uavsal_conv_gemm", C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     ("uavsal_conv_tile", C.c_int, [C.POINTER(ConvDesc)]),
+    ("uavsal_conv_uses_split", C.c_int, [C.POINTER(ConvDesc)]),
     ("uavsal_streamk_workspace_bytes", C.c_longlong, []),
     ("uavsal_conv_streamk_grid", C.c_int, [C.POINTER(ConvDesc)]),
     ("uavsal_dw3x3", C.c_int, [C.POINTER(DwDesc), C.c_void_p]),
@@ -154,7 +159,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.uavsal_abi_version() != 8:
+    if lib.uavsal_abi_version() != 10:
         raise RuntimeError("libuavsal_hip.so ABI version mismatch")
     for i, t in enumerate(DESC_TYPES):
         if lib.uavsal_sizeof_desc(i) != C.sizeof(t):

@@ -58,6 +58,35 @@ __device__ __forceinline__ uavsal_tile_walk xcd_tile_walk(int bid, int G, int nb
     return w;
 }
 
+// Split shadow of four fp32 values (uavsal_hip.h, uavsal_conv_desc.a_hi): hi = fp16_rtz(16 x), lo = fp16_rtz(16 x - hi),
+// packed as 4 halves each.  Round-toward-zero saturates at the largest finite half, so nothing becomes inf; the
+// residual 16 x - hi is exact in fp32 whatever the rounding of hi.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void uavsal_split4_f16(f32x4 x, u32x2& hi, u32x2& lo) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef __fp16 h2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        f2 v = q ? (f2){x.z, x.w} : (f2){x.x, x.y};
+        v = v * 16.0f;
+        const h2 h = __builtin_amdgcn_cvt_pkrtz(v.x, v.y);
+        const f2 r = v - (f2){(float)h.x, (float)h.y};
+        const h2 l = __builtin_amdgcn_cvt_pkrtz(r.x, r.y);
+        hi[q] = __builtin_bit_cast(unsigned, h);
+        lo[q] = __builtin_bit_cast(unsigned, l);
+    }
+}
+
+// store the split shadow of channels c..c+3 (c % 4 == 0) of one pixel: `row` points at the pixel's shadow row,
+// layout [group of 32 channels][hi 32 halves | lo 32 halves] (uavsal_hip.h)
+__device__ __forceinline__ void uavsal_store_split4(_Float16* row, int c, f32x4 v) {
+    u32x2 sh, sl;
+    uavsal_split4_f16(v, sh, sl);
+    _Float16* p = row + (c >> 5) * 64 + (c & 31);
+    *reinterpret_cast<u32x2*>(p) = sh;
+    *reinterpret_cast<u32x2*>(p + 32) = sl;
+}
+
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == UAVSAL_ACT_RELU6) return fminf(fmaxf(v, 0.f), 6.f);
     if (act == UAVSAL_ACT_SIGMOID) return 1.f / (1.f + expf(-v));

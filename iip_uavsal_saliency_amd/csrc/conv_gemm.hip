@@ -52,6 +52,9 @@ struct ConvK {
     int* sk_flag;        // ... and its "published" flag (0 at launch, reset by the consumer)
     int* err;            // device error word (UAVSAL_ERR_*)
     int sk_spin, sk_drop;
+    const _Float16* a_sp;      // pre-split A operand (split shadow, uavsal_hip.h) or null
+    _Float16* out_sp;          // optional split shadow of the output
+    int ldas, ldos;            // their row strides in halves
 };
 
 __device__ __forceinline__ long long row_off(int m, int HW, long long img_stride, int contig) {
@@ -108,7 +111,7 @@ __device__ __forceinline__ f32x4 prescale(f32x4 x) {
 // take as long as the MFMAs), so it is kept to: fma, v_med3 clamp, optional residual load+add,
 // one store with a wave-uniform base + 32-bit lane offset.  Written as a macro expanded inside
 // each kernel: handing the accumulator array to a function demotes it to scratch memory.
-#define UAVSAL_GEMM_EPILOGUE(ACC_SCALE, STG)                                                         \
+#define UAVSAL_GEMM_EPILOGUE(ACC_SCALE, STG, SPLIT_OUT)                                                       \
     {                                                                                                \
         /* the vector ConvTWA update is only compiled into the small-tile kernels (register budget) */ \
         const bool twa_ = (WM * WN == 1) && p.epi == UAVSAL_EPI_TWA;                                 \
@@ -183,7 +186,9 @@ __device__ __forceinline__ f32x4 prescale(f32x4 x) {
                             v += *reinterpret_cast<const f32x4*>(                                    \
                                 p.res + row_off(gm, p.HW, p.r_is, p.contig) * p.ldr + gn);           \
                         }                                                                            \
-                        *reinterpret_cast<f32x4*>(p.out + oo) = v;                                   \
+                        if (p.act < 100) *reinterpret_cast<f32x4*>(p.out + oo) = v;  /* >= 100: probe codes, no store */ \
+                        if ((SPLIT_OUT) && p.out_sp)  /* split shadow for the GEMMs that consume it */  \
+                            uavsal_store_split4(p.out_sp + row_off(gm, p.HW, p.o_is, p.contig) * p.ldos, gn, v); \
                     }                                                                                \
                 }                                                                                    \
                 __syncthreads();                                                                     \
@@ -597,7 +602,7 @@ void conv_gemm_kernel(const ConvK p) {
         }
 
         // ---- epilogue ------------------------------------------------------------------
-        UAVSAL_GEMM_EPILOGUE((PREC == UAVSAL_PREC_F16X3 ? F16X3_ACC_SCALE : 1.0f), smem)
+        UAVSAL_GEMM_EPILOGUE((PREC == UAVSAL_PREC_F16X3 ? F16X3_ACC_SCALE : 1.0f), smem, (PREC == UAVSAL_PREC_F16X3))
         tile += tile_step;
         if (tile >= tile_end) break;
     }
@@ -657,7 +662,6 @@ __global__ __launch_bounds__(256, SK ? 2 : ((WM * WN >= 4) ? 3 : 4)) void conv_g
     const uavsal_tile_walk walk = xcd_tile_walk(blockIdx.x, gridDim.x, p.nblk);
     int tile = walk.tile;
     const int tile_end = walk.end, tile_step = walk.stride;
-    if (!SK && tile >= tile_end) return;
     int m0 = 0, n0 = 0;
 
     // per-thread DMA coordinates: row (tid>>2) + it*64 of the tile, physical chunk tid&3
@@ -934,7 +938,7 @@ __global__ __launch_bounds__(256, SK ? 2 : ((WM * WN >= 4) ? 3 : 4)) void conv_g
                     e = bound(k + 1);
                     ++k;
                 }
-                UAVSAL_GEMM_EPILOGUE(1.0f, (smem + (S - 1) * STAGE))
+                UAVSAL_GEMM_EPILOGUE(1.0f, (smem + (S - 1) * STAGE), false)
             }
 #if !UAVSAL_SK_PREFETCH
             if (cur < w1) sg = open_segment(cur);
@@ -942,6 +946,13 @@ __global__ __launch_bounds__(256, SK ? 2 : ((WM * WN >= 4) ? 3 : 4)) void conv_g
         }
         return;
     }
+    // Whole-tile path, static walk (tiles slot, slot + gx, ... of the XCD's range).  Tried in round 2 and NOT kept:
+    // pulling every tile after a workgroup's first from a per-XCD atomic counter (fetched one tile ahead, so the
+    // next tile's first DMA stages are still requested before the epilogue).  2700 tiles over 768 resident
+    // workgroups leave CUs with 9..12 tiles, which the dynamic walk evens out -- but end to end it measured 2 %
+    // SLOWER (1330 vs 1360 frames/s, same box, two runs each): co-resident workgroups no longer sit on
+    // neighbouring tiles, and the kernel carried 21 more spilled SGPRs.
+    if (tile >= tile_end) return;
     setup_tile(tile);
     const int npre = nst < D ? nst : D;
     for (int t = 0; t < npre; ++t) issue_tile(t, t);
@@ -975,7 +986,231 @@ __global__ __launch_bounds__(256, SK ? 2 : ((WM * WN >= 4) ? 3 : 4)) void conv_g
             for (int t = 0; t < npre; ++t) issue_tile(t, t);
         }
 
-        UAVSAL_GEMM_EPILOGUE(1.0f, (smem + (S - 1) * STAGE))
+        UAVSAL_GEMM_EPILOGUE(1.0f, (smem + (S - 1) * STAGE), false)
+        if (!has_next) break;
+    }
+}
+
+// =====================================================================================
+// Split-fp16 path with PRE-SPLIT operands: LDS-DMA staged, S-stage ring, no conversion work.
+//
+// The register-staged kernel above re-splits the fp32 activations (hi = fp16(16 x), lo = fp16(16 x - hi)) in
+// VALU on every load, once per N tile that needs them, and pays a ds_write for every staged byte.  Here the
+// producer of the activation tensor has already written that split (the "split shadow", uavsal_hip.h: per
+// pixel and group of 32 channels one 128-byte line [32 hi | 32 lo]), and the weights are packed the same way
+// per (K step, output channel), so A and B both go global -> LDS by LDS-DMA exactly as in the fp32 kernel.
+// A stage holds two panels [A | B] of rows x 128 B (one K step of 32: hi chunks 0-3, lo chunks 4-7); every
+// DMA request fetches 8 rows x one FULL cache line (with planar hi / lo planes each request took half of 16
+// lines and L1 <- L2 moved 1.5x the useful bytes -- and that link, ~14 B/clk/CU, is what bounds this kernel:
+// profiles/r2_presplit_pmc.md).  Ring kept S-1 stages ahead with counted vmcnt + one raw s_barrier per K
+// step; MFMA loop lo*hi + hi*lo + hi*hi on v_mfma_f32_32x32x16_f16.  Every wave issues the same number of DMA
+// requests per stage (it owns whole 8-row pieces of both panels), which the counted wait relies on.
+// LDS swizzle: 16-byte slot s of row r lives at physical slot s ^ ((r >> 1) & 7): the 16 lanes of every
+// ds_read_b128 lane group then touch 16 different (row parity, slot) pairs = all 64 banks once.
+template <int WAVES_M, int WAVES_N, int WM, int WN, int TAPS, int S>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_gemm_h16_dma_kernel(const ConvK p) {
+    constexpr int NW = WAVES_M * WAVES_N;
+    constexpr int NT = NW * 64;
+    constexpr int BM = WAVES_M * WM * 32;
+    constexpr int BN = WAVES_N * WN * 32;
+    constexpr int KT = 32;                       // channels per K step: one 128-byte line (hi + lo) per row
+    constexpr int APAN = BM * 128, BPAN = BN * 128;
+    constexpr int STAGE = APAN + BPAN;
+    constexpr int AG = BM / 8 / NW, BG = BN / 8 / NW;       // 8-row pieces of A / B a wave stages
+    constexpr int PPW = AG + BG;                            // DMA requests per wave and stage
+    constexpr int D = S - 1;
+    static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0 && NW % 2 == 0, "every wave stages whole 8-row pieces");
+    static_assert(PPW * (D > 1 ? D - 1 : 0) < 64, "vmcnt immediate");
+    static_assert(STAGE >= 32 * BN * 4, "epilogue staging must fit one ring stage");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+
+    const int tid = threadIdx.x;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const uavsal_tile_walk walk = xcd_tile_walk(blockIdx.x, gridDim.x, p.nblk);
+    int tile = walk.tile;
+    const int tile_end = walk.end, tile_step = walk.stride;
+    if (tile >= tile_end) return;
+    int m0 = 0, n0 = 0;
+
+    // per-lane DMA coordinates: row (lane >> 3) of an 8-row piece, physical 16-byte slot lane & 7.  The swizzle
+    // is applied on the SOURCE address: the lane fetches logical slot = physical ^ ((row >> 1) & 7), and since
+    // a wave's pieces start at rows 8 * (wave + g * NW) with NW even, (row >> 1) & 7 is the same for all of them.
+    const int pr = lane >> 3;
+    const int ls = (lane & 7) ^ ((((wave_u & 1) << 2) | (pr >> 1)) & 7);
+    long long a_base[AG];            // half offset of the row's centre pixel in the shadow
+    int a_taps[AG];
+    bool a_ok[AG];
+    unsigned b_off[BG];              // byte offset of the row inside one K step's slab of the weights
+    bool b_ok[BG];
+    const char* zero = reinterpret_cast<const char*>(g_zero16);
+    auto setup_tile = [&](int t) {
+        const int tile_m = t / p.tiles_n;
+        const int tile_n = t - tile_m * p.tiles_n;
+        m0 = tile_m * BM;
+        n0 = tile_n * BN;
+#pragma unroll
+        for (int g = 0; g < AG; ++g) {
+            const int row = (wave_u + g * NW) * 8 + pr;
+            const int m = m0 + row;
+            a_ok[g] = m < p.M;
+            const int mm = a_ok[g] ? m : 0;
+            if (TAPS == 1) {
+                a_base[g] = row_off(mm, p.HW, p.a_is, p.contig) * p.ldas;
+                a_taps[g] = 0;
+            } else {
+                const int img = mm / p.HW;
+                const int pix = mm - img * p.HW;
+                const int y = pix / p.W, x = pix - y * p.W;
+                a_base[g] = ((long long)img * p.a_is + pix) * p.ldas;
+                int mask = 0;
+#pragma unroll
+                for (int tp = 0; tp < 9; ++tp) {
+                    const int yy = y + tp / 3 - 1, xx = x + tp % 3 - 1;
+                    if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) mask |= 1 << tp;
+                }
+                a_taps[g] = mask;
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < BG; ++g) {
+            const int n = n0 + (wave_u + g * NW) * 8 + pr;
+            b_ok[g] = n < p.Npad;
+            b_off[g] = (unsigned)(b_ok[g] ? n : 0) * 128u + ls * 16;
+        }
+    };
+
+    const int nst = p.ktiles;                    // K steps of 32
+    int it_kt = 0, it_tap = 0, it_ci = 0;        // running K position of the next stage to request
+    // The PPW requests of a stage are issued as one burst right after the barrier.  That burst blocks the wave
+    // for as long as the memory pipe takes to accept the stage (profiles/r2_presplit_pmc.md: DMA-only 345 us +
+    // MFMA-only 402 us = 602 us combined at K=1536, i.e. they hardly overlap); slotting the requests between
+    // MFMA groups (issue_piece one at a time) was tried and is SLOWER with hipcc's schedule (723 -> 783 us on
+    // the 128x128 tile, register spills on 256x256), so the burst stays.
+    bool is_kin = false;
+    char* is_As = nullptr;
+    const char* is_wk = nullptr;
+    long long is_aoff = 0;                       // wave-uniform part of the A source offset (halves)
+    int is_tap = 0;
+    auto begin_stage = [&](int stage) {
+        const int kt = it_kt;
+        is_kin = kt < nst;
+        is_As = smem + stage * STAGE;
+        is_tap = it_tap;
+        long long tap_off = 0;                   // (dy * W + dx) * ldas
+        if (TAPS == 9) {
+            const int ty = (is_tap * 11) >> 5;
+            tap_off = (long long)((ty - 1) * p.W + (is_tap - ty * 3 - 1)) * p.ldas;
+        }
+        is_aoff = tap_off + 2 * it_ci;           // channel group ci0 / 32 is 64 halves wide
+        is_wk = p.w + (size_t)kt * p.Npad * 128; // [K step][Npad][hi 64 B | lo 64 B]
+        ++it_kt;
+        if (TAPS == 9) { if (++it_tap == 9) { it_tap = 0; it_ci += KT; } }
+        else it_ci += KT;
+    };
+    auto issue_piece = [&](int q) {              // q: compile-time after unrolling
+        if (q < AG) {
+            const int g = q;
+            bool ok = a_ok[g] && is_kin;
+            if (TAPS == 9) ok = ok && ((a_taps[g] >> is_tap) & 1);
+            const long long off = a_base[g] + is_aoff + ls * 8;     // slot ls (0-3 hi, 4-7 lo) is 8 halves
+            const char* src = ok ? reinterpret_cast<const char*>(p.a_sp + off) : zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(is_As + (wave_u + g * NW) * 1024), 16, 0, 0);
+        } else {
+            const int g = q - AG;
+            const char* src = (b_ok[g] && is_kin) ? is_wk + b_off[g] : zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(is_As + APAN + (wave_u + g * NW) * 1024), 16, 0, 0);
+        }
+    };
+    auto issue_stage = [&](int stage) {
+        begin_stage(stage);
+#pragma unroll
+        for (int q = 0; q < PPW; ++q) issue_piece(q);
+    };
+
+    f32x16 acc[WM][WN];
+    const int wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
+    const int lr = lane & 31, lh = lane >> 5;
+
+    auto compute = [&](int stage) {
+        const char* As = smem + stage * STAGE;
+        const char* Bs = As + APAN;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int chunk = 2 * s + lh;        // hi chunk; the lo chunk is slot chunk + 4
+            u32x4 af[WM][2], bfr[WN][2];
+#pragma unroll
+            for (int i = 0; i < WM; ++i) {
+                const int row = (wm * WM + i) * 32 + lr;
+                const int sw = (row >> 1) & 7;
+                af[i][0] = *reinterpret_cast<const u32x4*>(As + row * 128 + ((chunk ^ sw) << 4));
+                af[i][1] = *reinterpret_cast<const u32x4*>(As + row * 128 + (((chunk + 4) ^ sw) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                const int row = (wn * WN + j) * 32 + lr;
+                const int sw = (row >> 1) & 7;
+                bfr[j][0] = *reinterpret_cast<const u32x4*>(Bs + row * 128 + ((chunk ^ sw) << 4));
+                bfr[j][1] = *reinterpret_cast<const u32x4*>(Bs + row * 128 + (((chunk + 4) ^ sw) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) {
+                    const f16x8 ah = __builtin_bit_cast(f16x8, af[i][0]), al = __builtin_bit_cast(f16x8, af[i][1]);
+                    const f16x8 bh = __builtin_bit_cast(f16x8, bfr[j][0]), bl = __builtin_bit_cast(f16x8, bfr[j][1]);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[i][j], 0, 0, 0);
+                }
+        }
+    };
+
+    setup_tile(tile);
+    const int npre = nst < D ? nst : D;
+    for (int t = 0; t < npre; ++t) issue_stage(t);
+    while (true) {
+        const int m0c = m0, n0c = n0;
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
+
+        int stage = 0, istage = npre % S;
+        for (int kt = 0; kt < nst; ++kt) {
+            // this wave's requests for stage kt have landed (the younger D-1 stages may still be in flight)
+            if (D > 1 && kt + D <= nst) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PPW * (D > 1 ? D - 1 : 0)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();        // every wave's have; and stage kt-1 (refilled next) is read out
+            if (kt + D < nst) {
+#ifdef UAVSAL_PROBE
+                if (p.act != 102)
+#endif
+                issue_stage(istage);
+                istage = (istage + 1 == S) ? 0 : istage + 1;
+            }
+#ifdef UAVSAL_PROBE
+            if (p.act != 101)
+#endif
+            compute(stage);
+            stage = (stage + 1 == S) ? 0 : stage + 1;
+        }
+
+        const bool has_next = (tile + tile_step) < tile_end;
+        __builtin_amdgcn_s_barrier();            // ring reads done (WAR for the next tile's DMA / the staging)
+        if (has_next) {
+            tile += tile_step;
+            setup_tile(tile);
+            it_kt = 0; it_tap = 0; it_ci = 0;
+            for (int t = 0; t < npre; ++t) issue_stage(t);
+        }
+        UAVSAL_GEMM_EPILOGUE(F16X3_ACC_SCALE, (smem + (S - 1) * STAGE), true)
         if (!has_next) break;
     }
 }
@@ -1120,6 +1355,44 @@ int launch_prec(const ConvK& k, int taps, int tile, hipStream_t stream) {
     }
 }
 
+
+template <int WAVES_M, int WAVES_N, int WM, int WN, int S>
+int launch_h16_dma(const ConvK& k0, int taps, hipStream_t stream) {
+    constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32, NT = WAVES_M * WAVES_N * 64;
+    constexpr int SMEM = S * (BM + BN) * 128;
+    ConvK k = k0;
+    k.tiles_n = (k.Cout + BN - 1) / BN;
+    k.nblk = ((k.M + BM - 1) / BM) * k.tiles_n;
+
+    if (taps == 1) {
+        static const int cap = resident_grid(conv_gemm_h16_dma_kernel<WAVES_M, WAVES_N, WM, WN, 1, S>, SMEM, NT);
+        const int grid = k.nblk < cap ? k.nblk : cap;
+        hipLaunchKernelGGL((conv_gemm_h16_dma_kernel<WAVES_M, WAVES_N, WM, WN, 1, S>), dim3(grid), dim3(NT), SMEM, stream, k);
+    } else {
+        static const int cap = resident_grid(conv_gemm_h16_dma_kernel<WAVES_M, WAVES_N, WM, WN, 9, S>, SMEM, NT);
+        const int grid = k.nblk < cap ? k.nblk : cap;
+        hipLaunchKernelGGL((conv_gemm_h16_dma_kernel<WAVES_M, WAVES_N, WM, WN, 9, S>), dim3(grid), dim3(NT), SMEM, stream, k);
+    }
+    return uavsal_launch_status();
+}
+
+// pre-split path: 256 x 256 / 128 x 256 on 8 waves, 128 x 128 on 4 (two workgroups per CU)
+int launch_h16(const ConvK& k, int taps, int tile, hipStream_t stream) {
+    if (tile == 6) return launch_h16_dma<2, 4, 4, 2, 2>(k, taps, stream);    // 2 x 64 KB ring
+    if (tile == 5) return launch_h16_dma<2, 4, 2, 2, 3>(k, taps, stream);    // 3 x 48 KB
+    return launch_h16_dma<2, 2, 2, 2, 2>(k, taps, stream);                   // 2 x 32 KB
+}
+
+// does this descriptor take the pre-split LDS-DMA path (with block tile `tile`)?
+bool split_eligible(const uavsal_conv_desc* d, int tile) {
+    if (d->prec != UAVSAL_PREC_F16X3 || !d->a_split) return false;
+    if (!(tile == 1 || tile == 5 || tile == 6) || (d->Cin % 32) || d->dw_w9c || d->epi != UAVSAL_EPI_AFFINE) return false;
+    if ((d->ldas & 63) || d->ldas < 2 * d->Cin || ((uintptr_t)d->a_split & 127)) return false;
+    // only the vector epilogue is built for these tiles
+    return d->act != UAVSAL_ACT_SIGMOID && !(d->ldc & 3) && !(d->Cout & 3) && uavsal_aligned16(d->out) &&
+           (!d->res || (!(d->ldr & 3) && uavsal_aligned16(d->res)));
+}
+
 // grid of the stream-K launch this descriptor would get with block tile `tile`, or 0 (whole tiles)
 int streamk_plan(const uavsal_conv_desc* d, int tile, int ktiles) {
     if (d->prec != UAVSAL_PREC_F32 || !(tile == 1 || tile == 3 || tile == 4) || d->dw_w9c ||
@@ -1177,6 +1450,19 @@ int pick_tile(long long M, int Cout, int prec) {
 
 }  // namespace
 
+static int effective_tile(const uavsal_conv_desc* d) {
+    int tile = (d->tile >= 1 && d->tile <= 6) ? d->tile
+                                             : pick_tile((long long)d->H * d->W * d->n_img, d->Cout, d->prec);
+    if (tile == 6) {   // the 256 x 256 tile only carries the vector epilogue
+        const bool vec = d->epi == UAVSAL_EPI_AFFINE && d->act != UAVSAL_ACT_SIGMOID && !(d->ldc & 3) &&
+                         !(d->Cout & 3) && uavsal_aligned16(d->out) &&
+                         (!d->res || (!(d->ldr & 3) && uavsal_aligned16(d->res)));
+        if (!vec || d->dw_w9c) tile = 5;
+    }
+    if (d->epi == UAVSAL_EPI_LSTM) tile = 4;     // the LSTM update lives in the 64x64 tile's vector epilogue
+    return tile;
+}
+
 extern "C" long long uavsal_streamk_workspace_bytes(void) {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
@@ -1194,19 +1480,35 @@ extern "C" int uavsal_conv_streamk_grid(const uavsal_conv_desc* d) {
 
 extern "C" int uavsal_conv_tile(const uavsal_conv_desc* d) {
     if (!d || d->n_img <= 0 || d->H <= 0 || d->W <= 0 || d->Cout <= 0) return UAVSAL_EINVAL;
-    if (d->epi == UAVSAL_EPI_LSTM) return 4;
-    if (d->tile >= 1 && d->tile <= 6) return d->tile;
-    return pick_tile((long long)d->H * d->W * d->n_img, d->Cout, d->prec);
+    return effective_tile(d);
+}
+
+extern "C" int uavsal_conv_uses_split(const uavsal_conv_desc* d) {
+    if (!d || d->n_img <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0) return 0;
+    return split_eligible(d, effective_tile(d)) ? 1 : 0;
 }
 
 extern "C" int uavsal_conv_gemm(const uavsal_conv_desc* d, uavsal_stream_t stream) {
-    if (!d || !d->a || !d->w || !d->out) return UAVSAL_EINVAL;
+    if (!d || !d->w || !d->out) return UAVSAL_EINVAL;
+    if (!d->a && !(d->a_split && d->epi == UAVSAL_EPI_AFFINE)) return UAVSAL_EINVAL;
     if (d->n_img <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0) return UAVSAL_EINVAL;
     if (d->taps != 1 && d->taps != 9) return UAVSAL_ESHAPE;
     if (d->prec < 0 || d->prec > 3) return UAVSAL_ESHAPE;
-    if ((d->Cin & 3) || (d->lda & 3) || d->lda < d->Cin) return UAVSAL_EALIGN;
+    if (d->Cin & 3) return UAVSAL_EALIGN;
+    if (d->a && ((d->lda & 3) || d->lda < d->Cin || !uavsal_aligned16(d->a))) return UAVSAL_EALIGN;
     if (d->epi != UAVSAL_EPI_LSTM && d->ldc < d->Cout) return UAVSAL_ESHAPE;
-    if (!uavsal_aligned16(d->a) || !uavsal_aligned16(d->w)) return UAVSAL_EALIGN;
+    if (!uavsal_aligned16(d->w)) return UAVSAL_EALIGN;
+    if (d->out_split && ((d->ldos & 63) || d->ldos < 2 * d->Cout || ((uintptr_t)d->out_split & 127)))
+        return UAVSAL_EALIGN;
+    if (d->out_split && d->prec != UAVSAL_PREC_F16X3) return UAVSAL_ESHAPE;   // only those kernels carry the store
+    if (d->out_split) {  // the shadow is written by the vector epilogue only
+        const int t = effective_tile(d);
+        const bool twa_vec = d->epi == UAVSAL_EPI_TWA && (t == 3 || t == 4) && !(d->ldx & 3) && !(d->lda & 3) &&
+                             uavsal_aligned16(d->aux);
+        const bool vec = (d->epi == UAVSAL_EPI_AFFINE || twa_vec) && d->act != UAVSAL_ACT_SIGMOID && !(d->ldc & 3) &&
+                         !(d->Cout & 3) && uavsal_aligned16(d->out) && (!d->res || (!(d->ldr & 3) && uavsal_aligned16(d->res)));
+        if (!vec) return UAVSAL_ESHAPE;
+    }
     if (d->taps == 9 && (d->Cin % 32)) return UAVSAL_ESHAPE;
     if ((d->scale == nullptr) != (d->bias == nullptr)) return UAVSAL_EINVAL;
     if (d->res && d->epi != UAVSAL_EPI_LSTM && d->ldr < d->Cout) return UAVSAL_ESHAPE;
@@ -1254,15 +1556,12 @@ extern "C" int uavsal_conv_gemm(const uavsal_conv_desc* d, uavsal_stream_t strea
     k.sk_part = nullptr; k.sk_flag = nullptr; k.err = nullptr;
     k.sk_spin = d->sk_spin_limit > 0 ? d->sk_spin_limit : (1 << 22);
     k.sk_drop = d->sk_debug_drop;
-    int tile = (d->tile >= 1 && d->tile <= 6) ? d->tile : pick_tile(M, d->Cout, d->prec);
-    if (tile == 6) {   // the 256 x 256 tile only carries the vector epilogue
-        const bool vec = d->epi == UAVSAL_EPI_AFFINE && d->act != UAVSAL_ACT_SIGMOID && !(d->ldc & 3) &&
-                         !(d->Cout & 3) && uavsal_aligned16(d->out) &&
-                         (!d->res || (!(d->ldr & 3) && uavsal_aligned16(d->res)));
-        if (!vec || d->dw_w9c) tile = 5;
-    }
-    if (d->epi == UAVSAL_EPI_LSTM) tile = 4;     // the LSTM update lives in the 64x64 tile's vector epilogue
+    const int tile = effective_tile(d);
     hipStream_t s = (hipStream_t)stream;
+    k.a_sp = (const _Float16*)d->a_split; k.ldas = d->ldas;
+    k.out_sp = (_Float16*)d->out_split; k.ldos = d->ldos;
+    if (split_eligible(d, tile)) return launch_h16(k, d->taps, tile, s);
+    if (!d->a) return UAVSAL_EINVAL;             // pre-split operands given but the shape is not eligible
     {
         const int G = streamk_plan(d, tile, k.ktiles);
         if (G > 0) {

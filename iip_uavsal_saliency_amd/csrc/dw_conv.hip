@@ -23,6 +23,8 @@ struct DwK {
     const float* scale;
     const float* bias;
     float* out;
+    _Float16* out_split;                     // split shadow written INSTEAD of `out` (or null)
+    int ldos;
     int ldi, ldo, H, W, Ho, Wo, C4, dil, act;
     int tiles_x, tiles_y, n_img;
     long long total;   // work items = n_img * tiles_y * tiles_x * C4
@@ -95,7 +97,12 @@ __global__ __launch_bounds__(256) void dw3x3_kernel(const DwK p) {
                 v.x = fminf(fmaxf(v.x, 0.f), 6.f); v.y = fminf(fmaxf(v.y, 0.f), 6.f);
                 v.z = fminf(fmaxf(v.z, 0.f), 6.f); v.w = fminf(fmaxf(v.w, 0.f), 6.f);
             }
-            *reinterpret_cast<f32x4*>(p.out + (((size_t)n * p.Ho + oy) * p.Wo + ox) * p.ldo + c) = v;
+            const size_t opix = ((size_t)n * p.Ho + oy) * p.Wo + ox;
+            if (p.out_split) {   // the projection GEMM that consumes this tensor stages it pre-split (LDS-DMA)
+                uavsal_store_split4(p.out_split + opix * p.ldos, c, v);
+            } else {
+                *reinterpret_cast<f32x4*>(p.out + opix * p.ldo + c) = v;
+            }
         }
     }
 }
@@ -244,15 +251,21 @@ int launch_dw(DwK k, hipStream_t s) {
 }  // namespace
 
 extern "C" int uavsal_dw3x3(const uavsal_dw_desc* d, uavsal_stream_t stream) {
-    if (!d || !d->in || !d->w9c || !d->scale || !d->bias || !d->out) return UAVSAL_EINVAL;
+    if (!d || !d->in || !d->w9c || !d->scale || !d->bias) return UAVSAL_EINVAL;
+    if (!d->out && !d->out_split) return UAVSAL_EINVAL;
     if (d->n_img <= 0 || d->H <= 0 || d->W <= 0 || d->C <= 0) return UAVSAL_EINVAL;
-    if ((d->C & 3) || (d->ldi & 3) || (d->ldo & 3) || d->ldi < d->C || d->ldo < d->C) return UAVSAL_EALIGN;
-    if (!uavsal_aligned16(d->in) || !uavsal_aligned16(d->out) || !uavsal_aligned16(d->w9c) ||
+    if ((d->C & 3) || (d->ldi & 3) || d->ldi < d->C) return UAVSAL_EALIGN;
+    if (d->out && ((d->ldo & 3) || d->ldo < d->C || !uavsal_aligned16(d->out))) return UAVSAL_EALIGN;
+    if (d->out_split && ((d->ldos & 63) || d->ldos < 2 * d->C || (d->C & 31) || ((uintptr_t)d->out_split & 127)))
+        return UAVSAL_EALIGN;
+    if (d->out_split && d->dilation != 1) return UAVSAL_ESHAPE;
+    if (!uavsal_aligned16(d->in) || !uavsal_aligned16(d->w9c) ||
         !uavsal_aligned16(d->scale) || !uavsal_aligned16(d->bias)) return UAVSAL_EALIGN;
     if (d->stride != 1 && d->stride != 2) return UAVSAL_ESHAPE;
     if (d->dilation < 1 || (d->stride == 2 && d->dilation != 1)) return UAVSAL_ESHAPE;
     DwK k;
     k.in = d->in; k.w9c = d->w9c; k.scale = d->scale; k.bias = d->bias; k.out = d->out;
+    k.out_split = (_Float16*)d->out_split; k.ldos = d->ldos;
     k.ldi = d->ldi; k.ldo = d->ldo; k.H = d->H; k.W = d->W;
     k.Ho = (d->H - 1) / d->stride + 1; k.Wo = (d->W - 1) / d->stride + 1;
     k.C4 = d->C / 4; k.dil = d->dilation; k.act = d->act; k.n_img = d->n_img;

@@ -86,6 +86,7 @@ struct BilK {
     const float* in; float* out;
     int ldi, ldo, Hi, Wi, Ho, Wo, C4, src_mod, src_div;
     float sy, sx; long long total;
+    _Float16* out_split; int ldos;                    // optional split shadow of the output
 };
 
 __global__ __launch_bounds__(256) void bilinear_kernel(const BilK p) {
@@ -109,7 +110,9 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const BilK p) {
     const f32x4 v10 = *reinterpret_cast<const f32x4*>(b + ((size_t)y1 * p.Wi + x0) * p.ldi);
     const f32x4 v11 = *reinterpret_cast<const f32x4*>(b + ((size_t)y1 * p.Wi + x1) * p.ldi);
     const f32x4 r = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
-    *reinterpret_cast<f32x4*>(p.out + (((size_t)n * p.Ho + oy) * p.Wo + ox) * p.ldo + c) = r;
+    const size_t opix = ((size_t)n * p.Ho + oy) * p.Wo + ox;
+    *reinterpret_cast<f32x4*>(p.out + opix * p.ldo + c) = r;
+    if (p.out_split) uavsal_store_split4(p.out_split + opix * p.ldos, c, r);
 }
 
 // ---------------------------------------------------------------- temporal differences
@@ -231,6 +234,9 @@ extern "C" int uavsal_bilinear_ac(const uavsal_bilinear_desc* d, uavsal_stream_t
     k.src_mod = d->src_mod; k.src_div = d->src_div;
     k.sy = d->Ho > 1 ? (float)(d->Hi - 1) / (float)(d->Ho - 1) : 0.f;
     k.sx = d->Wo > 1 ? (float)(d->Wi - 1) / (float)(d->Wo - 1) : 0.f;
+    if (d->out_split && ((d->ldos & 63) || d->ldos < 2 * d->C || (d->C & 31) || ((uintptr_t)d->out_split & 127)))
+        return UAVSAL_EALIGN;
+    k.out_split = (_Float16*)d->out_split; k.ldos = d->ldos;
     k.total = (long long)d->n_out * d->Ho * d->Wo * k.C4;
     int nblk; int e = grid_for(k.total, &nblk); if (e) return e;
     hipLaunchKernelGGL(bilinear_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, k);

@@ -28,26 +28,35 @@ def _down(n: int) -> int:
 
 
 class V:
-    """A channel slice [coff, coff+C) of an NHWC buffer `[n*h*w, ld]`."""
-    __slots__ = ("t", "ld", "coff", "n", "h", "w", "c")
+    """A channel slice [coff, coff+C) of an NHWC buffer `[n*h*w, ld]`.  `sp`: the buffer's split shadow (fp16,
+    `[pixel][ld/32][hi 32 | lo 32]`, include/uavsal_hip.h) when some GEMM stages this tensor pre-split; `t` is
+    None for a tensor that only exists as its shadow (depthwise outputs)."""
+    __slots__ = ("t", "ld", "coff", "n", "h", "w", "c", "sp", "key")
 
-    def __init__(self, t, n, h, w, c, ld=None, coff=0):
+    def __init__(self, t, n, h, w, c, ld=None, coff=0, sp=None, key=None):
         self.t, self.n, self.h, self.w, self.c = t, n, h, w, c
         self.ld = ld if ld is not None else c
         self.coff = coff
+        self.sp, self.key = sp, key
 
     @property
     def ptr(self):
-        return self.t.data_ptr() + 4 * self.coff
+        return None if self.t is None else self.t.data_ptr() + 4 * self.coff
+
+    @property
+    def sp_ptr(self):
+        """Address of this view inside the shadow: `coff` = pixel offset * ld + channel offset (a multiple of 32)."""
+        pix, ch = divmod(self.coff, self.ld)
+        assert ch % 32 == 0 and self.ld % 32 == 0
+        return self.sp.data_ptr() + 2 * (pix * 2 * self.ld + (ch // 32) * 64)
 
     def slice(self, coff, c):
-        return V(self.t, self.n, self.h, self.w, c, self.ld, self.coff + coff)
+        return V(self.t, self.n, self.h, self.w, c, self.ld, self.coff + coff, self.sp, self.key)
 
     def frames(self, first, count):
         """Images [first, first+count) as a view (pointer offset only)."""
-        v = V(self.t, count, self.h, self.w, self.c, self.ld, self.coff)
-        v.coff = self.coff + first * self.h * self.w * self.ld
-        return v
+        return V(self.t, count, self.h, self.w, self.c, self.ld, self.coff + first * self.h * self.w * self.ld,
+                 self.sp, self.key)
 
 
 class Engine:
@@ -91,6 +100,13 @@ class Engine:
         self._wcache: Dict[tuple, object] = wcache if wcache is not None else {}
         # persistent-state mode: the recurrent state lives in `hprev` (NHWC) across calls, see run()
         self.persistent = bool(persistent)
+        # f16x3: tensors that an eligible GEMM consumes are ALSO kept as split shadows (hi/lo fp16 planes) written
+        # by their producers, so that GEMM stages both operands by LDS-DMA with no conversion work.  The sizing
+        # pass finds out which buffers are wanted (`_split_want`) and which cannot have one because a producer
+        # does not write shadows (`_no_shadow`).
+        self.split_mode = precision == "f16x3" and bool(getattr(model, "presplit", True))
+        self._split_want = set()
+        self._no_shadow = set()
         self.ops_meta: List[dict] = []
         self.stage_ranges: Dict[str, tuple] = {}
         self.named: Dict[str, V] = {}
@@ -101,8 +117,10 @@ class Engine:
         # pass 1 sizes the shared scratch, pass 2 records the launches
         self._dry = True
         self._build()
+        self._split_want -= self._no_shadow
         for k, need in self._scratch_need.items():
-            self._scratch[k] = torch.empty(max(need, 4), dtype=torch.float32, device=self.device)
+            self._scratch[k] = torch.empty(max(need, 4), dtype=torch.float16 if k[0] == "Ds" else torch.float32,
+                                           device=self.device)
         self._lane = 0
         self._dry = False
         self.ops_meta, self.stage_ranges, self.named = [], {}, {}
@@ -125,15 +143,44 @@ class Engine:
 
     # ------------------------------------------------------------------ memory helpers
     def _buf(self, name, n, h, w, c) -> V:
+        sp = None
         if self._dry:
             t = _Fake()
         else:
             t = torch.empty(n * h * w * c, dtype=torch.float32, device=self.device)
             self._keep.append(t)
-        v = V(t, n, h, w, c)
+            if name in self._split_want and c % 32 == 0:
+                sp = torch.empty(2 * n * h * w * c, dtype=torch.float16, device=self.device)
+                self._keep.append(sp)
+        v = V(t, n, h, w, c, sp=sp, key=name)
         if name:
             self.named[name] = v
         return v
+
+    def _scr_split(self, n, h, w, c) -> V:
+        """A depthwise output that exists only as its split shadow (scratch, per lane)."""
+        numel = 2 * n * h * w * c
+        k = ("Ds", self._lane)
+        if self._dry:
+            self._scratch_need[k] = max(self._scratch_need.get(k, 0), numel)
+            return V(None, n, h, w, c, sp=_Fake(), key=k)
+        return V(None, n, h, w, c, sp=self._scratch[k], key=k)
+
+    def _would_split(self, n_img, h, w, cin, cout, taps, act, has_res, ldc=None, ldr=None) -> bool:
+        """Would `uavsal_conv_gemm` take the pre-split LDS-DMA path for this GEMM if its A operand had a
+        shadow?  (Shape question only: asked with dummy aligned pointers.)"""
+        if not self.split_mode:
+            return False
+        d = L.ConvDesc()
+        P_ = 1 << 20
+        d.a, d.lda, d.a_img_stride = P_, cin, h * w
+        d.a_split, d.ldas = P_, 2 * cin
+        d.w, d.out, d.ldc, d.o_img_stride = P_, P_, (cout if ldc is None else ldc), h * w
+        if has_res:
+            d.res, d.ldr, d.r_img_stride = P_, (cout if ldr is None else ldr), h * w
+        d.n_img, d.H, d.W, d.Cin, d.Cout, d.taps = n_img, h, w, cin, cout, taps
+        d.prec, d.act, d.epi, d.tile = self.prec, act, L.EPI_AFFINE, 0
+        return int(self.lib.uavsal_conv_uses_split(C.byref(d))) == 1
 
     def _scr(self, kind, n, h, w, c) -> V:
         """Scratch for the expanded tensors of an inverted-residual block, one pool per (kind, lane):
@@ -180,8 +227,10 @@ class Engine:
             self._wcache[key] = (self._dev(P.pad_vec(s, n, 1.0)), self._dev(P.pad_vec(b, n, 0.0)))
         return self._wcache[key]
 
-    def _convw(self, conv, sl=None, gate_interleave=0):
-        key = ("w", id(conv), sl, self.prec_name, gate_interleave)
+    def _convw(self, conv, sl=None, gate_interleave=0, natural=False):
+        """`natural`: the pre-split LDS-DMA path takes the weights as [K step][Cout][hi 32 | lo 32] ('f16x3i')."""
+        layout = "f16x3i" if natural else self.prec_name
+        key = ("w", id(conv), sl, layout, gate_interleave)
         if key not in self._wcache:
             w = conv.weight.detach()
             if sl is not None:
@@ -189,8 +238,14 @@ class Engine:
             if gate_interleave:      # ConvLSTM: row g*hid + c  ->  4*c + g  (gates i,f,o,g adjacent)
                 hid = gate_interleave
                 w = w.reshape(4, hid, *w.shape[1:]).permute(1, 0, 2, 3, 4).reshape(4 * hid, *w.shape[1:])
-            self._wcache[key] = self._dev(P.pack_conv_weight(w, self.prec_name))
+            self._wcache[key] = self._dev(P.pack_conv_weight(w, layout))
         return self._wcache[key]
+
+    def _tile_of(self, n_img, h, w, cout, epi) -> int:
+        d = L.ConvDesc()
+        d.n_img, d.H, d.W, d.Cout, d.prec, d.epi, d.tile = n_img, h, w, cout, self.prec, epi, 0
+        d.out = 1 << 20
+        return int(self.lib.uavsal_conv_tile(C.byref(d)))
 
     # ------------------------------------------------------------------ op recorders
     def _meta(self, **kw):
@@ -217,11 +272,30 @@ class Engine:
         byts = 4.0 * n_img * hw * (cin + cout) + 4.0 * cin * cout * taps
         self._meta(kind="conv%d" % (3 if taps == 9 else 1), name=name, flops=flops, bytes=byts,
                    M=n_img * hw, K=cin * taps, Nc=cout)
+        # split shadows (f16x3): can this launch write one for its output / read its input pre-split?
+        shadow_out = False
+        if self.split_mode:
+            aligned = cout % 4 == 0 and out.ld % 4 == 0 and (res is None or res.ld % 4 == 0)
+            if epi == L.EPI_AFFINE:
+                shadow_out = aligned and act != L.ACT_SIGMOID
+            elif epi == L.EPI_TWA:       # the vector ConvTWA update only exists in the 1x1-fragment tiles
+                shadow_out = aligned and self._tile_of(n_img, a.h, a.w, cout, epi) in (3, 4)
+            if self._dry:
+                if not shadow_out and out.key is not None:
+                    self._no_shadow.add(out.key)
+                if (a.key is not None and a.key not in self._no_shadow and dw is None and strides is None
+                        and epi == L.EPI_AFFINE and a.ld % 32 == 0 and (a.coff % a.ld) % 32 == 0 and self._would_split(
+                            n_img, a.h, a.w, cin, cout, taps, act, res is not None, out.ld, res.ld if res is not None else None)):
+                    self._split_want.add(a.key)
         if self._dry:
             return
         d = L.ConvDesc()
         st = strides or {}
         d.a, d.lda, d.a_img_stride = a.ptr, a.ld, st.get("a", hin * win if dw is not None else hw)
+        if a.sp is not None and dw is None and strides is None and epi == L.EPI_AFFINE:
+            d.a_split, d.ldas = a.sp_ptr, 2 * a.ld
+        if out.sp is not None and shadow_out:
+            d.out_split, d.ldos = out.sp_ptr, 2 * out.ld
         if dw is not None:
             key = ("dw", id(dw[0]))
             if key not in self._wcache:
@@ -231,7 +305,6 @@ class Engine:
             d.dw_w9c, d.dw_scale, d.dw_bias = w9.data_ptr(), s_.data_ptr(), b_.data_ptr()
             d.dw_stride, d.dw_Hin, d.dw_Win = dw[2], hin, win
             self.ops_meta[-1]["fused_dw"] = True
-        d.w = self._convw(conv, wslice, gate_interleave).data_ptr()
         if bn is not None:
             s, b = self._affine(bn, cout)
             d.scale, d.bias = s.data_ptr(), b.data_ptr()
@@ -260,6 +333,13 @@ class Engine:
             d.sk_ws, d.sk_ws_bytes = ws.data_ptr(), ws.numel()
         d.err = self._err
         d.sk_spin_limit, d.sk_debug_drop = self._sk_debug      # test hooks (model._sk_debug), normally (0, 0)
+        # weights last: their 16-bit packing depends on which kernel the descriptor selects
+        d.w = 1 << 20
+        split = int(self.lib.uavsal_conv_uses_split(C.byref(d))) == 1
+        if a.t is None and not split:
+            raise RuntimeError("%s: its input only exists as a split shadow but the GEMM is not eligible" % name)
+        d.w = self._convw(conv, wslice, gate_interleave, natural=split).data_ptr()
+        self.ops_meta[-1]["split"] = split
         self.ops_meta[-1]["tile"] = int(self.lib.uavsal_conv_tile(C.byref(d)))
         self.ops_meta[-1]["streamk"] = int(self.lib.uavsal_conv_streamk_grid(C.byref(d)))
         self._add(self.lib.uavsal_plan_add_conv, d, "plan_add_conv(%s)" % name)
@@ -280,7 +360,12 @@ class Engine:
         d = L.DwDesc()
         d.inp, d.ldi = a.ptr, a.ld
         d.w9c, d.scale, d.bias = w9.data_ptr(), s.data_ptr(), b.data_ptr()
-        d.out, d.ldo = out.ptr, out.ld
+        if out.t is None:            # the projection GEMM stages this tensor pre-split: no fp32 copy
+            d.out, d.ldo = None, out.ld
+            d.out_split, d.ldos = out.sp_ptr, 2 * out.ld
+            self.ops_meta[-1]["split_out"] = True
+        else:
+            d.out, d.ldo = out.ptr, out.ld
         d.n_img, d.H, d.W, d.C = a.n, a.h, a.w, c
         d.stride, d.dilation, d.act = stride, dilation, L.ACT_RELU6
         self.ops_meta[-1]["kernel"] = L.DW_KERNEL.get(int(self.lib.uavsal_dw_variant(C.byref(d))), "dw3x3")
@@ -294,6 +379,8 @@ class Engine:
         d.inp, d.ldi, d.Hi, d.Wi = a.ptr, a.ld, a.h, a.w
         d.out, d.ldo, d.Ho, d.Wo = out.ptr, out.ld, out.h, out.w
         d.n_out, d.C = out.n, a.c
+        if out.sp is not None:
+            d.out_split, d.ldos = out.sp_ptr, 2 * out.ld
         d.src_mod, d.src_div = (out.n if src_mod is None else src_mod), src_div
         self._add(self.lib.uavsal_plan_add_bilinear, d, "plan_add_bilinear(%s)" % name)
 
@@ -323,9 +410,14 @@ class Engine:
             self.conv(name + ".dwpl", e, pl, plbn, out, final_act, res=x if blk.use_res_connect else None,
                       dw=(dwc, dwbn, stride))
             return
-        dd = self._scr("D", x.n, ho, wo, blk.hidden)
+        res = x if blk.use_res_connect else None
+        if dil == 1 and self._would_split(x.n, ho, wo, blk.hidden, out.c, 1, final_act, res is not None, out.ld,
+                                          res.ld if res is not None else None):
+            dd = self._scr_split(x.n, ho, wo, blk.hidden)      # D only ever exists as hi/lo fp16 planes
+        else:
+            dd = self._scr("D", x.n, ho, wo, blk.hidden)
         self.dw(name + ".dw", e, dwc, dwbn, dd, stride, dil)
-        self.conv(name + ".pl", dd, pl, plbn, out, final_act, res=x if blk.use_res_connect else None)
+        self.conv(name + ".pl", dd, pl, plbn, out, final_act, res=res)
 
     def _mark(self, stage, start):
         self.stage_ranges[stage] = (start, len(self.ops_meta))
@@ -352,6 +444,9 @@ class Engine:
         # ---- boundary: state and priors NCHW -> NHWC
         s0 = len(self.ops_meta)
         h0 = self._buf("h0", self.n_seq, h, w, 256)
+        # buffers written by kernels that do not produce split shadows
+        self._no_shadow.update(("h0", "c0", "gauss_in", "ob_in", "f0", "ctx_sum", "lstm_pre", "lstm_c", "twa_pre"))
+        self._no_shadow.update("st%d_dif" % i for i in range(len(m.st_layer)))
         lstm_model = getattr(m, "rnn_type", "twa") == "lstm"
         c0 = self._buf("c0", self.n_seq, h, w, 256) if lstm_model else None
         g0 = self._buf("gauss_in", N, h, w, 8)

@@ -166,6 +166,7 @@ class UAVSal(nn.Module):
         self.fuse_dw = None             # None: engine default (off; see engine.py)
         self.use_lanes = True           # independent branches on parallel streams / graph branches
         self.stream_k = True            # fp32 GEMMs: split K across workgroups when whole tiles leave CUs idle
+        self.presplit = True            # f16x3: producers also write hi/lo fp16 shadows, GEMMs stage them by LDS-DMA
         # A device-side error (a stream-K hand-off that timed out) always NaN-fills the returned map and state.
         # True: forward also waits for its own launches (one event wait) and raises before returning;
         # False: fully asynchronous, the RuntimeError comes from the next forward / `check_errors()`.
@@ -253,7 +254,8 @@ class UAVSal(nn.Module):
                 return self._engine(device, n_seq, seq_len, H, W, ctx_mode, taps, in_dtype)
         key = (str(device), n_seq, seq_len, H, W, self.time_dims if ctx_mode == "tile" else seq_len,
                ctx_mode, self.precision, bool(taps), in_dtype, bool(self.use_graph), self.rnn_type, self.fuse_dw, bool(self.use_lanes),
-               bool(self.stream_k), bool(self.persistent_state), tuple(getattr(self, "_sk_debug", (0, 0))))
+               bool(self.stream_k), bool(self.persistent_state), tuple(getattr(self, "_sk_debug", (0, 0))),
+               bool(self.presplit))
         eng = self._engines.get(key)
         if eng is None:
             while len(self._engines) >= max(1, int(self.max_engines)):

@@ -43,8 +43,33 @@ def _streamk_outcome(ws, what):
         raise RuntimeError("stream-K workspace not clean after the launch")
 
 
+def split_shadow(x: torch.Tensor) -> torch.Tensor:
+    """Split shadow (include/uavsal_hip.h) of a dense fp32 NHWC tensor `[..., C]`, C % 32 == 0, computed with
+    torch: fp16 `[..., C/32, 2, 32]` with [.., 0, :] = hi = fp16(16 x) and [.., 1, :] = lo = fp16(16 x - hi).
+    (The kernels round hi toward zero; any hi works as long as lo is the residual.)"""
+    c = x.shape[-1]
+    if c % 32:
+        raise RuntimeError("split shadows need C % 32 == 0")
+    x16 = x.float().reshape(*x.shape[:-1], c // 32, 32) * 16.0
+    hi = x16.clamp(-65504.0, 65504.0).to(torch.float16)
+    lo = (x16 - hi.float()).clamp(-65504.0, 65504.0).to(torch.float16)
+    return torch.stack([hi, lo], -2).contiguous()
+
+
+def merge_shadow(sp: torch.Tensor) -> torch.Tensor:
+    """fp32 `[..., C]` back from a split shadow `[..., C/32, 2, 32]`."""
+    v = (sp[..., 0, :].float() + sp[..., 1, :].float()) / 16.0
+    return v.reshape(*v.shape[:-2], v.shape[-2] * 32)
+
+
+def _empty_shadow(n, h, w, c, device):
+    if c % 32:
+        raise RuntimeError("split shadows need C % 32 == 0")
+    return torch.empty((n, h, w, c // 32, 2, 32), dtype=torch.float16, device=device)
+
+
 def conv_gemm(x, weight, scale=None, bias=None, act=L.ACT_NONE, res=None, out=None, prec="f32", tile=0, dw=None,
-              stream_k=False, sk_spin_limit=0, sk_debug_drop=0):
+              stream_k=False, sk_spin_limit=0, sk_debug_drop=0, split_in=False, split_out=False):
     """Dense 1x1 / 3x3 conv (+ folded BN, activation, residual).  `weight` [Cout,Cin,k,k] (cpu or cuda).
     `dw=(w[C,1,3,3], scale[C], bias[C], stride)`: x is the expanded tensor and the depthwise 3x3 + BN + ReLU6
     in front of this 1x1 conv is computed inside the GEMM's loader (fused inverted-residual tail)."""
@@ -56,17 +81,25 @@ def conv_gemm(x, weight, scale=None, bias=None, act=L.ACT_NONE, res=None, out=No
     if out is None:
         out = torch.empty((n, h, w, cout), dtype=torch.float32, device=x.device)
     op, ldc, *_ = _nhwc_view(out)
-    wp = P.pack_conv_weight(weight, prec).to(x.device)
-    keep = [wp]
+    keep = []
     d = L.ConvDesc()
     d.a, d.lda, d.a_img_stride = ap, lda, hin * win
+    if split_in:          # pre-split A operand: the GEMM stages it by LDS-DMA (f16x3, eligible shapes)
+        if not x.is_contiguous():
+            raise RuntimeError("split_in needs a dense NHWC tensor")
+        xs = split_shadow(x)
+        keep.append(xs)
+        d.a_split, d.ldas = xs.data_ptr(), 2 * cin
+    shadow = None
+    if split_out:
+        shadow = _empty_shadow(n, h, w, cout, x.device)
+        d.out_split, d.ldos = shadow.data_ptr(), 2 * cout
     if dw is not None:
         w9 = P.pack_dw_weight(dw[0]).to(x.device)
         ds, db = dw[1].float().contiguous().to(x.device), dw[2].float().contiguous().to(x.device)
         keep += [w9, ds, db]
         d.dw_w9c, d.dw_scale, d.dw_bias = w9.data_ptr(), ds.data_ptr(), db.data_ptr()
         d.dw_stride, d.dw_Hin, d.dw_Win = stride, hin, win
-    d.w = wp.data_ptr()
     if scale is not None:
         npad = P.roundup(cout, 32)
         s = P.pad_vec(scale, npad, 1.0).to(x.device)
@@ -84,11 +117,18 @@ def conv_gemm(x, weight, scale=None, bias=None, act=L.ACT_NONE, res=None, out=No
         keep.append(ws)
         d.sk_ws, d.sk_ws_bytes = ws.data_ptr(), ws.numel()
         d.sk_spin_limit, d.sk_debug_drop = sk_spin_limit, sk_debug_drop
+    d.w = 1 << 20
+    uses_split = int(lib.uavsal_conv_uses_split(C.byref(d))) == 1
+    if split_in and not uses_split:
+        raise RuntimeError("this shape / tile does not take the pre-split path")
+    wp = P.pack_conv_weight(weight, "f16x3i" if uses_split else prec).to(x.device)
+    keep.append(wp)
+    d.w = wp.data_ptr()
     L.check(lib.uavsal_conv_gemm(C.byref(d), _stream(x)), "uavsal_conv_gemm")
     torch.cuda.current_stream(x.device).synchronize()   # `keep` must outlive the launch
     if stream_k:
         _streamk_outcome(ws, "uavsal_conv_gemm")
-    return out
+    return (out, shadow) if split_out else out
 
 
 def twa_step(x_t, h_prev, pre_t, w_h, prec="f32", tile=0, stream_k=False):
@@ -117,22 +157,29 @@ def twa_step(x_t, h_prev, pre_t, w_h, prec="f32", tile=0, stream_k=False):
     return out
 
 
-def dw3x3(x, weight, scale, bias, stride=1, dilation=1, act=L.ACT_RELU6, out=None):
+def dw3x3(x, weight, scale, bias, stride=1, dilation=1, act=L.ACT_RELU6, out=None, split_out=False):
+    """`split_out`: the result is written as a split shadow (fp16 `[n,h,w,C/32,2,32]`) instead of fp32."""
     lib = L.load()
     ip, ldi, n, h, w, c = _nhwc_view(x)
     ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
-    if out is None:
-        out = torch.empty((n, ho, wo, c), dtype=torch.float32, device=x.device)
-    op, ldo, *_ = _nhwc_view(out)
+    if split_out:
+        sp = _empty_shadow(n, ho, wo, c, x.device)
+        op, ldo = None, c
+    else:
+        if out is None:
+            out = torch.empty((n, ho, wo, c), dtype=torch.float32, device=x.device)
+        op, ldo, *_ = _nhwc_view(out)
     w9 = P.pack_dw_weight(weight).to(x.device)
     s, b = scale.float().contiguous().to(x.device), bias.float().contiguous().to(x.device)
     d = L.DwDesc()
     d.inp, d.ldi, d.w9c, d.scale, d.bias = ip, ldi, w9.data_ptr(), s.data_ptr(), b.data_ptr()
     d.out, d.ldo = op, ldo
     d.n_img, d.H, d.W, d.C, d.stride, d.dilation, d.act = n, h, w, c, stride, dilation, act
+    if split_out:
+        d.out_split, d.ldos = sp.data_ptr(), 2 * c
     L.check(lib.uavsal_dw3x3(C.byref(d), _stream(x)), "uavsal_dw3x3")
     torch.cuda.current_stream(x.device).synchronize()
-    return out
+    return sp if split_out else out
 
 
 def stem_conv(x_nchw, weight, scale, bias):
@@ -158,7 +205,7 @@ def stem_conv(x_nchw, weight, scale, bias):
     return out
 
 
-def bilinear_ac(x, ho, wo, out=None, n_out=None, src_mod=None, src_div=1):
+def bilinear_ac(x, ho, wo, out=None, n_out=None, src_mod=None, src_div=1, split_out=False):
     lib = L.load()
     ip, ldi, n, h, w, c = _nhwc_view(x)
     n_out = n if n_out is None else n_out
@@ -168,8 +215,12 @@ def bilinear_ac(x, ho, wo, out=None, n_out=None, src_mod=None, src_div=1):
     d = L.BilinearDesc()
     d.inp, d.ldi, d.Hi, d.Wi, d.out, d.ldo, d.Ho, d.Wo = ip, ldi, h, w, op, ldo, ho, wo
     d.n_out, d.C, d.src_mod, d.src_div = n_out, c, (n_out if src_mod is None else src_mod), src_div
+    if split_out:
+        sp = _empty_shadow(n_out, ho, wo, c, x.device)
+        d.out_split, d.ldos = sp.data_ptr(), 2 * c
     L.check(lib.uavsal_bilinear_ac(C.byref(d), _stream(x)), "uavsal_bilinear_ac")
-    return out
+    torch.cuda.current_stream(x.device).synchronize()
+    return (out, sp) if split_out else out
 
 
 def tdiff(x, seq_len):

@@ -36,7 +36,9 @@ def roundup(x: int, m: int) -> int:
 
 def pack_conv_weight(w: torch.Tensor, prec: str) -> torch.Tensor:
     """`w` [Cout, Cin, kh, kw] (kh=kw in {1,3}) -> packed byte tensor (uint8, 1-D) in the layout
-    `uavsal_conv_gemm` expects for `prec` in {'f32','bf16','bf16x3','f16x3'}."""
+    `uavsal_conv_gemm` expects for `prec` in {'f32','bf16','bf16x3','f16x3'}, or 'f16x3i': the f16x3
+    values with the natural k order, hi and lo of one (K step, output channel) interleaved into one 128-byte
+    line [Kpad/32][Npad][hi 32 | lo 32] (the pre-split LDS-DMA path, uavsal_conv_uses_split)."""
     w = w.detach().float().cpu()
     cout, cin, kh, kw = w.shape
     taps = kh * kw
@@ -58,12 +60,14 @@ def pack_conv_weight(w: torch.Tensor, prec: str) -> torch.Tensor:
     if prec == "f32":
         return m.contiguous().view(torch.uint8).reshape(-1)
     # 16-bit layouts are K-step-major: [Kpad/32][panel][Npad][32] -- one K step is one contiguous run
-    idx = torch.tensor(_K_PERM32, dtype=torch.long)
+    idx = torch.tensor(list(range(32)) if prec == "f16x3i" else _K_PERM32, dtype=torch.long)
     m = m.view(npad, kpad // 32, 32)[:, :, idx]                 # [npad, steps, 32]
-    if prec == "f16x3":
+    if prec in ("f16x3", "f16x3i"):
         m = m * 64.0
         hi = m.to(torch.float16)
         lo = (m - hi.float()).to(torch.float16)
+        if prec == "f16x3i":
+            return torch.stack([hi, lo], 2).permute(1, 0, 2, 3).contiguous().view(torch.uint8).reshape(-1)
         return torch.stack([hi, lo], 0).permute(2, 0, 1, 3).contiguous().view(torch.uint8).reshape(-1)
     hi = m.to(torch.bfloat16)
     if prec == "bf16":

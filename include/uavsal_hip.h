@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define UAVSAL_ABI_VERSION 8
+#define UAVSAL_ABI_VERSION 10
 
 /* argument errors */
 #define UAVSAL_EINVAL   (-1)  /* null pointer / non-positive size */
@@ -139,6 +139,21 @@ typedef struct uavsal_conv_desc {
      * UAVSAL_ERR_STREAMK in `*err` -- the caller must treat the output as invalid and re-zero the flag block
      * (uavsal_guard / uavsal_plan_status do both checks for a plan). */
     void* sk_ws; int64_t sk_ws_bytes;
+    /* Pre-split operands (UAVSAL_PREC_F16X3 only).  The "split shadow" of an fp32 NHWC activation tensor x with
+     * channel stride ld (ld % 32 == 0) is an fp16 buffer [pixel][ld / 32][2][32]: for every group of 32
+     * channels, 32 halves hi = fp16_rtz(16*x) followed by 32 halves lo = fp16_rtz(16*x - hi) -- exactly what the
+     * register-staged kernel computes from `a` on every load, in the same number of bytes as x, laid out so
+     * that the 32 channels one K step needs are ONE 128-byte line per pixel (planar hi / lo planes made every
+     * request half a line and the L1 <- L2 traffic 1.5x the useful bytes: profiles/r2_presplit_pmc.md).
+     * Row stride `ld*s` is in halves (2 * ld for a dense shadow); a channel slice starts at a multiple of 32.
+     * When a_split is given (and Cin % 32 == 0, tile 1 / 5 / 6, vector epilogue) the GEMM stages BOTH operands
+     * with LDS-DMA and does no conversion work; `w` must then be packed 'f16x3i' (packing.py: per K step and
+     * output channel the same [32 hi | 32 lo] line; uavsal_conv_uses_split tells which).  `a` may be NULL
+     * then unless epi == UAVSAL_EPI_TWA.
+     * out_split (UAVSAL_PREC_F16X3, vector epilogue only; Cout % 32 == 0): the result is additionally written as
+     * a split shadow for the GEMMs that consume it -- the fp32 copy stays for every other consumer. */
+    const void* a_split;  int32_t ldas;
+    void* out_split;      int32_t ldos;
     int32_t* err;            /* device word OR-ed with UAVSAL_ERR_* (NULL: the last int32 of sk_ws' 64 KB flag block) */
     int32_t sk_spin_limit;   /* polls before a stream-K owner gives up on one piece; 0 = default (1 << 22, seconds) */
     int32_t sk_debug_drop;   /* TEST HOOK: 1 + index of the stream-K workgroup that withholds its "published" flag (< 0: all do); 0 = none */
@@ -147,6 +162,9 @@ typedef struct uavsal_conv_desc {
 int uavsal_conv_gemm(const uavsal_conv_desc* d, uavsal_stream_t stream);
 /* block tile `uavsal_conv_gemm` will use for this descriptor (1..6, see `tile`); no launch */
 int uavsal_conv_tile(const uavsal_conv_desc* d);
+/* 1 when `uavsal_conv_gemm` will take the pre-split LDS-DMA path for this descriptor (a_split set, shape
+ * eligible) and therefore expects `w` in the 'f16x3i' packing, else 0; no launch */
+int uavsal_conv_uses_split(const uavsal_conv_desc* d);
 /* size of the optional stream-K workspace (see uavsal_conv_desc.sk_ws) */
 long long uavsal_streamk_workspace_bytes(void);
 /* workgroups of the stream-K launch `uavsal_conv_gemm` will use for this descriptor, 0 = whole tiles; no launch */
@@ -166,6 +184,9 @@ typedef struct uavsal_dw_desc {
     const float* w9c;  const float* scale;  const float* bias;
     float*       out;  int32_t ldo;
     int32_t n_img, H, W, C, stride, dilation, act;
+    /* optional: write the result as a split shadow (see uavsal_conv_desc) INSTEAD of fp32 -- the only consumer
+     * of a depthwise output is the projection GEMM (model.py:94).  `out` may then be NULL.  dilation 1 only. */
+    void* out_split;  int32_t ldos;
 } uavsal_dw_desc;
 
 int uavsal_dw3x3(const uavsal_dw_desc* d, uavsal_stream_t stream);
@@ -206,6 +227,7 @@ typedef struct uavsal_bilinear_desc {
     const float* in;  int32_t ldi;  int32_t Hi, Wi;
     float* out;       int32_t ldo;  int32_t Ho, Wo;
     int32_t n_out, C, src_mod, src_div;
+    void* out_split;  int32_t ldos;              /* optional split shadow, written IN ADDITION to `out` */
 } uavsal_bilinear_desc;
 
 int uavsal_bilinear_ac(const uavsal_bilinear_desc* d, uavsal_stream_t stream);

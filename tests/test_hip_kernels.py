@@ -361,3 +361,77 @@ def test_rejects_bad_arguments(ops):
         ops.conv_gemm(torch.zeros((1, 4, 4, 16), device="cuda"), torch.zeros(8, 16, 3, 3), None, None)
     with pytest.raises(RuntimeError):                      # one frame: reference raises too (model.py:194)
         ops.tdiff(torch.zeros((1, 4, 4, 32), device="cuda"), 1)
+
+
+# ---- pre-split (LDS-DMA) fp16 GEMM path: uavsal_conv_desc.a_split, out_split -----------------------------
+SPLIT_CASES = [
+    # n, h, w, cin, cout, taps, act, res, tile
+    (2, 12, 20, 256, 1536, 1, 1, False, 1),     # expand, 128x128 (2 x 32 KB ring)
+    (2, 12, 20, 256, 1536, 1, 1, False, 5),     # 128x256, 8 waves, 3-stage ring
+    (2, 23, 40, 256, 1536, 1, 1, False, 6),     # 256x256, 8 waves, M tail (1840 rows)
+    (1, 23, 40, 1536, 256, 1, 0, True, 5),      # projection with residual, long K
+    (1, 23, 40, 1536, 256, 1, 0, True, 6),
+    (3, 7, 5, 320, 256, 1, 1, False, 1),        # M = 105 < one tile, Cin = 320 (10 K steps)
+    (2, 9, 13, 96, 64, 1, 0, False, 1),         # Cout = 64 < tile width, 3 K steps
+    (1, 12, 20, 448, 256, 9, 1, False, 5),      # conv_last shape: 3x3, zero padding through the zero page
+    (2, 9, 11, 64, 96, 9, 1, True, 1),          # 3x3, ragged everything
+    (1, 45, 80, 256, 256, 9, 0, False, 6),      # 3x3 on the 256x256 tile
+    (2, 45, 80, 32, 256, 1, 1, False, 1),       # one K step
+]
+
+
+@pytest.mark.parametrize("case", SPLIT_CASES)
+def test_conv_presplit_lds_dma(ops, case):
+    """The pre-split path == F.conv2d fp32 on CPU at the f16x3 tolerance, and the split shadow it writes for
+    its own output reconstructs that output to fp16x2 precision."""
+    n, h, w, cin, cout, taps, act, use_res, tile = case
+    k = 3 if taps == 9 else 1
+    x = rnd((n, cin, h, w), 81, 2.0)
+    wt = rnd((cout, cin, k, k), 82, 1.0 / np.sqrt(cin * taps))
+    scale = rnd((cout,), 83) * 0.5 + 1.0
+    bias = rnd((cout,), 84)
+    res = rnd((n, cout, h, w), 85) if use_res else None
+    ref = act_ref(F.conv2d(x, wt, padding=k // 2) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1), act)
+    if use_res:
+        ref = ref + res
+    got, sp = ops.conv_gemm(nhwc(x), wt, scale, bias, act=act, res=nhwc(res) if use_res else None,
+                            prec="f16x3", tile=tile, split_in=True, split_out=True)
+    mag = max(1.0, ref.abs().max().item())
+    err = (nchw(got) - ref).abs().max().item()
+    assert err <= TOL["f16x3"] * 8.0 * mag, (case, err)
+    # shadow of the output: hi + lo == 16 * out up to the two roundings (2^-21 relative) 
+    rec = ops.merge_shadow(sp)
+    serr = (rec - got).abs().max().item()
+    assert serr <= 2e-6 * mag, (case, serr)
+    # and it matches the register-staged kernel on the same operands to accumulation-order noise
+    old = ops.conv_gemm(nhwc(x), wt, scale, bias, act=act, res=nhwc(res) if use_res else None, prec="f16x3",
+                        tile=tile if tile in (1, 5, 6) else 0)
+    assert (old - got).abs().max().item() <= 2e-5 * mag
+
+
+def test_presplit_requires_eligible_shape(ops):
+    x = nhwc(rnd((1, 48, 9, 13), 91))
+    wt = rnd((64, 48, 1, 1), 92)
+    with pytest.raises(RuntimeError):           # Cin % 32 != 0: no LDS-DMA path
+        ops.conv_gemm(x, wt, prec="f16x3", split_in=True)
+
+
+@pytest.mark.parametrize("case", [(2, 45, 80, 1536, 1), (1, 23, 41, 96, 2), (2, 12, 20, 960, 1), (1, 180, 320, 32, 1)])
+def test_depthwise_split_output(ops, case):
+    """dw3x3 writing its result as a split shadow instead of fp32 (what the projection GEMM stages by DMA)."""
+    n, h, w, c, stride = case
+    x = rnd((n, c, h, w), 51, 2.0)
+    wt = rnd((c, 1, 3, 3), 52, 0.4)
+    scale = rnd((c,), 53) * 0.5 + 1.0
+    bias = rnd((c,), 54)
+    ref = torch.clamp(F.conv2d(x, wt, stride=stride, padding=1, groups=c) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1), 0, 6)
+    got = ops.merge_shadow(ops.dw3x3(nhwc(x), wt, scale, bias, stride=stride, split_out=True))
+    assert (nchw(got) - ref).abs().max().item() <= 1e-5
+    plain = ops.dw3x3(nhwc(x), wt, scale, bias, stride=stride)
+    assert (got - plain).abs().max().item() <= 6.0 * 2 ** -20       # two fp16 roundings of values in [0, 6]
+
+
+def test_bilinear_split_output(ops):
+    x = nhwc(rnd((3, 64, 12, 20), 71, 3.0))
+    out, sp = ops.bilinear_ac(x, 45, 80, split_out=True)
+    assert (ops.merge_shadow(sp) - out).abs().max().item() <= 3.0 * 2 ** -20
