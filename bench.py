@@ -146,8 +146,8 @@ def kernel_rooflines(eng, prec, iters=5):
             key = kernel_symbol(prec, m["tile"], 9 if m["kind"] == "conv3" else 1, m.get("streamk", 0), m.get("split", False))
             if m.get("fused_dw"):
                 key = "conv_gemm_kernel<%s, true>" % (H16_INST[m["tile"]] % (PREC_ID[prec], 1))
-        elif m["kind"] == "dw":
-            key = m["kernel"]                  # uavsal_dw_variant: the instance the library launches
+        elif m["kind"] in ("dw", "fused_ir"):
+            key = m["kernel"]                  # uavsal_dw_variant / the fused block instance the library launches
         else:
             key = m["kind"]
         if os.environ.get("UAVSAL_BENCH_OPS"):
@@ -238,6 +238,9 @@ def main():
     ap.add_argument("--stream-k", type=int, default=1, help="fp32 GEMMs: stream-K when whole tiles would idle CUs")
     ap.add_argument("--presplit", type=int, default=1, help="f16x3: producers also write split shadows and the eligible GEMMs "
                     "stage both operands by LDS-DMA (0: every GEMM re-splits its fp32 input while staging)")
+    ap.add_argument("--fuse-blocks", type=int, default=1, help="features[1..7] as one fused launch per block (0: three launches)")
+    ap.add_argument("--sync-errors", type=int, default=-1, help="-1: model default (forward_clips is asynchronous: device errors "
+                    "poison the outputs and raise at the next call); 1: wait for every call's launches and raise before returning")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
@@ -273,6 +276,8 @@ def main():
     model.use_lanes = bool(args.lanes)
     model.stream_k = bool(args.stream_k)
     model.presplit = bool(args.presplit)
+    model.fuse_blocks = bool(args.fuse_blocks)
+    model.sync_errors = None if args.sync_errors < 0 else bool(args.sync_errors)
 
     x_cpu, cb_cpu = make_clips(C, T, H, W, seed=shard.first)       # this rank's clips
     x = x_cpu.to(device)

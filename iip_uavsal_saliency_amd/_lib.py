@@ -96,7 +96,16 @@ class CopyDesc(C.Structure):
                 ("row_floats", C.c_int64), ("rows", C.c_int32)]
 
 
-DESC_TYPES = [ConvDesc, DwDesc, StemDesc, BilinearDesc, TdiffDesc, TsumDesc, LayoutDesc, PostDesc, GuardDesc, CopyDesc]
+class FusedIrDesc(C.Structure):
+    _fields_ = [("inp", _f), ("ldi", C.c_int32), ("w1", _f), ("scale1", _f), ("bias1", _f),
+                ("wd", _f), ("scale_d", _f), ("bias_d", _f), ("w2", _f), ("scale2", _f), ("bias2", _f),
+                ("res", _f), ("ldr", C.c_int32), ("out", _f), ("ldo", C.c_int32),
+                ("n_img", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32),
+                ("hidden", C.c_int32), ("Cout", C.c_int32), ("stride", C.c_int32)]
+
+
+DESC_TYPES = [ConvDesc, DwDesc, StemDesc, BilinearDesc, TdiffDesc, TsumDesc, LayoutDesc, PostDesc, GuardDesc, CopyDesc,
+              FusedIrDesc]
 
 # every symbol include/uavsal_hip.h declares: (name, restype, argtypes)
 SYMBOLS = [
@@ -115,6 +124,9 @@ SYMBOLS = [
     ("uavsal_postprocess", C.c_int, [C.POINTER(PostDesc), C.c_void_p]),
     ("uavsal_guard", C.c_int, [C.POINTER(GuardDesc), C.c_void_p]),
     ("uavsal_copy_rows", C.c_int, [C.POINTER(CopyDesc), C.c_void_p]),
+    ("uavsal_fused_ir", C.c_int, [C.POINTER(FusedIrDesc), C.c_void_p]),
+    ("uavsal_fused_ir_supported", C.c_int, [C.POINTER(FusedIrDesc)]),
+    ("uavsal_plan_add_fused_ir", C.c_int, [C.c_void_p, C.POINTER(FusedIrDesc)]),
     ("uavsal_plan_add_copy", C.c_int, [C.c_void_p, C.POINTER(CopyDesc)]),
     ("uavsal_plan_create", C.c_void_p, []),
     ("uavsal_plan_destroy", None, [C.c_void_p]),
@@ -128,6 +140,7 @@ SYMBOLS = [
     ("uavsal_plan_error_word", C.c_void_p, [C.c_void_p]),
     ("uavsal_plan_add_guard", C.c_int, [C.c_void_p, _f, C.c_int64, _f, C.c_int64, _f, C.c_int64]),
     ("uavsal_plan_status", C.c_int, [C.c_void_p, C.c_int]),
+    ("uavsal_plan_patch_ptr", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     ("uavsal_plan_set_lane", C.c_int, [C.c_void_p, C.c_int]),
     ("uavsal_plan_add_fork", C.c_int, [C.c_void_p, C.c_int]),
     ("uavsal_plan_add_join", C.c_int, [C.c_void_p, C.c_int]),
@@ -159,7 +172,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.uavsal_abi_version() != 10:
+    if lib.uavsal_abi_version() != 11:
         raise RuntimeError("libuavsal_hip.so ABI version mismatch")
     for i, t in enumerate(DESC_TYPES):
         if lib.uavsal_sizeof_desc(i) != C.sizeof(t):

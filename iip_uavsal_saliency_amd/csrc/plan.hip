@@ -8,7 +8,7 @@
 #include "common.h"
 
 namespace {
-enum OpKind { OP_CONV = 0, OP_DW, OP_STEM, OP_BILINEAR, OP_TDIFF, OP_TSUM, OP_LAYOUT, OP_GUARD, OP_COPY, OP_FORK, OP_JOIN };
+enum OpKind { OP_CONV = 0, OP_DW, OP_STEM, OP_BILINEAR, OP_TDIFF, OP_TSUM, OP_LAYOUT, OP_GUARD, OP_COPY, OP_FUSED_IR, OP_FORK, OP_JOIN };
 constexpr int MAX_LANES = 8;
 
 // Lanes: lane 0 is the caller's stream; lanes 1..7 are private streams on which independent
@@ -29,6 +29,7 @@ struct Op {
         uavsal_layout_desc lay;
         uavsal_guard_desc guard;
         uavsal_copy_desc copy;
+        uavsal_fused_ir_desc fir;
     } u;
 };
 
@@ -43,6 +44,7 @@ int run_op(const Op& op, uavsal_stream_t s) {
         case OP_LAYOUT: return uavsal_layout(&op.u.lay, s);
         case OP_GUARD: return uavsal_guard(&op.u.guard, s);
         case OP_COPY: return uavsal_copy_rows(&op.u.copy, s);
+        case OP_FUSED_IR: return uavsal_fused_ir(&op.u.fir, s);
     }
     return UAVSAL_EINVAL;
 }
@@ -169,6 +171,36 @@ UAVSAL_ADD(uavsal_plan_add_tdiff, OP_TDIFF, td, uavsal_tdiff_desc)
 UAVSAL_ADD(uavsal_plan_add_tsum, OP_TSUM, ts, uavsal_tsum_desc)
 UAVSAL_ADD(uavsal_plan_add_layout, OP_LAYOUT, lay, uavsal_layout_desc)
 UAVSAL_ADD(uavsal_plan_add_copy, OP_COPY, copy, uavsal_copy_desc)
+UAVSAL_ADD(uavsal_plan_add_fused_ir, OP_FUSED_IR, fir, uavsal_fused_ir_desc)
+
+extern "C" int uavsal_plan_patch_ptr(uavsal_plan* p, int op, int slot, void* ptr) {
+    if (!p || op < 0 || op >= (int)p->ops.size() || !ptr) return UAVSAL_EINVAL;
+    if (p->exec) return UAVSAL_ESTATE;
+    Op& o = p->ops[op];
+    switch (o.kind) {
+        case OP_CONV:
+            if (!uavsal_aligned16(ptr)) return UAVSAL_EALIGN;
+            if (slot == 0) o.u.conv.a = (const float*)ptr;
+            else if (slot == 1) o.u.conv.out = (float*)ptr;
+            else return UAVSAL_EINVAL;
+            return 0;
+        case OP_STEM:
+            if (slot == 0) { o.u.stem.in = (const float*)ptr; o.u.stem.in_u8 = nullptr; }
+            else if (slot == 1) { o.u.stem.in_u8 = (const uint8_t*)ptr; o.u.stem.in = nullptr; }
+            else return UAVSAL_EINVAL;
+            return 0;
+        case OP_LAYOUT:
+            if (slot == 0) o.u.lay.in = (const float*)ptr;
+            else if (slot == 1) o.u.lay.out = (float*)ptr;
+            else return UAVSAL_EINVAL;
+            return 0;
+        case OP_GUARD:
+            if (slot < 0 || slot > 2 || !o.u.guard.buf[slot]) return UAVSAL_EINVAL;
+            o.u.guard.buf[slot] = (float*)ptr;
+            return 0;
+    }
+    return UAVSAL_ESHAPE;
+}
 
 extern "C" int uavsal_plan_size(const uavsal_plan* p) { return p ? (int)p->ops.size() : UAVSAL_EINVAL; }
 
@@ -276,6 +308,7 @@ extern "C" int uavsal_sizeof_desc(int which) {
         case 7: return (int)sizeof(uavsal_post_desc);
         case 8: return (int)sizeof(uavsal_guard_desc);
         case 9: return (int)sizeof(uavsal_copy_desc);
+        case 10: return (int)sizeof(uavsal_fused_ir_desc);
     }
     return UAVSAL_EINVAL;
 }

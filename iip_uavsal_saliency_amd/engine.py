@@ -105,9 +105,15 @@ class Engine:
         # pass finds out which buffers are wanted (`_split_want`) and which cannot have one because a producer
         # does not write shadows (`_no_shadow`).
         self.split_mode = precision == "f16x3" and bool(getattr(model, "presplit", True))
+        self.fuse_blocks = bool(getattr(model, "fuse_blocks", True))
         self._split_want = set()
         self._no_shadow = set()
         self.ops_meta: List[dict] = []
+        self._op_idx: Dict[str, int] = {}
+        # launch-loop mode reads the caller's tensors in place and writes straight into fresh outputs
+        # (uavsal_plan_patch_ptr); a captured graph replays fixed addresses and keeps the staging copies
+        self.inplace = not use_graph
+        self._hold = None
         self.stage_ranges: Dict[str, tuple] = {}
         self.named: Dict[str, V] = {}
         self._scratch_need: Dict[tuple, int] = {}
@@ -123,7 +129,7 @@ class Engine:
                                            device=self.device)
         self._lane = 0
         self._dry = False
-        self.ops_meta, self.stage_ranges, self.named = [], {}, {}
+        self.ops_meta, self.stage_ranges, self.named, self._op_idx = [], {}, {}, {}
         self.plan = C.c_void_p(self.lib.uavsal_plan_create())
         if not self.plan:
             raise RuntimeError("uavsal_plan_create failed")
@@ -249,7 +255,11 @@ class Engine:
 
     # ------------------------------------------------------------------ op recorders
     def _meta(self, **kw):
+        self._op_idx[kw.get("name")] = len(self.ops_meta)       # == index of the op in the native plan
         self.ops_meta.append(kw)
+
+    def _patch(self, name, slot, ptr):
+        L.check(self.lib.uavsal_plan_patch_ptr(self.plan, self._op_idx[name], slot, ptr), "plan_patch_ptr(%s)" % name)
 
     def _add(self, fn, desc, what):
         r = fn(self.plan, C.byref(desc))
@@ -392,9 +402,61 @@ class Engine:
         d.inp, d.out, d.n_img, d.C, d.HW, d.ld, d.to_nhwc, d.Cpad = src_ptr, dst_ptr, n, c, hw, ld, to_nhwc, cpad
         self._add(self.lib.uavsal_plan_add_layout, d, "plan_add_layout(%s)" % name)
 
+    def fused_block(self, name, x: V, blk, out: V) -> bool:
+        """The whole inverted-residual block as ONE launch (uavsal_fused_ir: the expanded tensors stay in LDS),
+        where an instance exists -- the bandwidth-bound small-channel blocks features[1..7].  False = not taken."""
+        seq = blk.conv
+        if not self.fuse_blocks or getattr(blk, "dilation", 1) != 1:
+            return False
+        d = L.FusedIrDesc()
+        d.Cin, d.hidden, d.Cout, d.stride = x.c, blk.hidden, out.c, blk.stride
+        d.w1 = (1 << 20) if blk.expand_ratio != 1 else None
+        if not int(self.lib.uavsal_fused_ir_supported(C.byref(d))):
+            return False
+        ho, wo = (x.h - 1) // blk.stride + 1, (x.w - 1) // blk.stride + 1
+        self._meta(kind="fused_ir", name=name, kernel="fused_ir_kernel<%d, %d, %d, %d>" % (x.c, blk.hidden, out.c, blk.stride),
+                   flops=2.0 * x.n * ((x.h * x.w * x.c * blk.hidden if blk.expand_ratio != 1 else 0)
+                                      + ho * wo * blk.hidden * (9 + out.c)),
+                   bytes=4.0 * x.n * (x.h * x.w * x.c + ho * wo * out.c * (2 if blk.use_res_connect else 1)))
+        if out.key is not None:
+            self._no_shadow.add(out.key)            # this kernel does not write split shadows
+        if self._dry:
+            return True
+        if blk.expand_ratio != 1:
+            pw, pwbn, dwc, dwbn, pl, plbn = seq[0][0], seq[0][1], seq[1][0], seq[1][1], seq[2], seq[3]
+        else:
+            pw, pwbn, dwc, dwbn, pl, plbn = None, None, seq[0][0], seq[0][1], seq[1], seq[2]
+        key = ("fused", id(dwc))
+        if key not in self._wcache:
+            ws = {}
+            if pw is not None:
+                s_, b_ = P.fold_bn(pwbn)
+                ws["w1"] = self._dev(pw.weight.detach().float().cpu().reshape(blk.hidden, x.c).t().contiguous())
+                ws["s1"], ws["b1"] = self._dev(s_), self._dev(b_)
+            s_, b_ = P.fold_bn(dwbn)
+            ws["wd"], ws["sd"], ws["bd"] = self._dev(P.pack_dw_weight(dwc.weight)), self._dev(s_), self._dev(b_)
+            s_, b_ = P.fold_bn(plbn)
+            ws["w2"] = self._dev(pl.weight.detach().float().cpu().reshape(out.c, blk.hidden).t().contiguous())
+            ws["s2"], ws["b2"] = self._dev(s_), self._dev(b_)
+            self._wcache[key] = ws
+        ws = self._wcache[key]
+        d.inp, d.ldi = x.ptr, x.ld
+        if pw is not None:
+            d.w1, d.scale1, d.bias1 = ws["w1"].data_ptr(), ws["s1"].data_ptr(), ws["b1"].data_ptr()
+        d.wd, d.scale_d, d.bias_d = ws["wd"].data_ptr(), ws["sd"].data_ptr(), ws["bd"].data_ptr()
+        d.w2, d.scale2, d.bias2 = ws["w2"].data_ptr(), ws["s2"].data_ptr(), ws["b2"].data_ptr()
+        if blk.use_res_connect:
+            d.res, d.ldr = x.ptr, x.ld
+        d.out, d.ldo = out.ptr, out.ld
+        d.n_img, d.H, d.W = x.n, x.h, x.w
+        self._add(self.lib.uavsal_plan_add_fused_ir, d, "plan_add_fused_ir(%s)" % name)
+        return True
+
     def ir_block(self, name, x: V, blk, out: V, final_act=L.ACT_NONE):
         """pw-expand + BN + ReLU6 -> dw3x3 + BN + ReLU6 -> pw-linear + BN [+ x]
         (dwBlock, reference model.py:74-103; torchvision InvertedResidual)."""
+        if final_act == L.ACT_NONE and self.fused_block(name, x, blk, out):
+            return
         seq = blk.conv
         stride, dil = blk.stride, getattr(blk, "dilation", 1)
         if blk.expand_ratio != 1:
@@ -434,6 +496,7 @@ class Engine:
             self.cb0_in = torch.empty((N, 8, h, w), dtype=torch.float32, device=dev)
             self.cb1_in = torch.empty((N, 20, h, w), dtype=torch.float32, device=dev)
             self.state_in = torch.zeros((self.n_seq, 256, h, w), dtype=torch.float32, device=dev)
+            self.zero_state = torch.zeros((self.n_seq, 256, h, w), dtype=torch.float32, device=dev)    # never written
             self.state_out = torch.empty((self.n_seq, 256, h, w), dtype=torch.float32, device=dev)
             self.cstate_in = torch.zeros((self.n_seq, 256, h, w), dtype=torch.float32, device=dev)
             self.cstate_out = torch.empty((self.n_seq, 256, h, w), dtype=torch.float32, device=dev)
@@ -451,36 +514,14 @@ class Engine:
         c0 = self._buf("c0", self.n_seq, h, w, 256) if lstm_model else None
         g0 = self._buf("gauss_in", N, h, w, 8)
         o0 = self._buf("ob_in", N, h, w, 20)
-        if self._dry:
-            lay = (("gauss.in", 8), ("ob.in", 20))
-            if not self.persistent:
-                lay = (("state.in", 256),) + lay + ((("cstate.in", 256),) if lstm_model else ())
-            for nm, c in lay:
-                self._meta(kind="layout", name=nm, flops=0.0, bytes=8.0 * N * c * hw)
-        else:
-            if not self.persistent:      # persistent mode: h0 / c0 ARE the state, staged only on demand (run())
-                self.layout("state.in", self.state_in.data_ptr(), h0.ptr, self.n_seq, 256, hw, 256, 1)
-                if lstm_model:
-                    self.layout("cstate.in", self.cstate_in.data_ptr(), c0.ptr, self.n_seq, 256, hw, 256, 1)
-            self.layout("gauss.in", self.cb0_in.data_ptr(), g0.ptr, N, 8, hw, 8, 1)
-            self.layout("ob.in", self.cb1_in.data_ptr(), o0.ptr, N, 20, hw, 20, 1)
+        if not self.persistent:          # persistent mode: h0 / c0 ARE the state, staged only on demand (run())
+            names = ["state.in"] + (["cstate.in"] if lstm_model else [])
+            for nm, src, dst in zip(names, ("state_in", "cstate_in"), (h0, c0)):
+                if self._dry:
+                    self._meta(kind="layout", name=nm, flops=0.0, bytes=8.0 * self.n_seq * 256 * hw)
+                else:
+                    self.layout(nm, getattr(self, src).data_ptr(), dst.ptr, self.n_seq, 256, hw, 256, 1)
         self._mark("boundary_in", s0)
-
-        # ---- gaussian / observed prior nets (model.py:349,352): they depend only on the caller's priors,
-        #      so they run on lanes 1 and 2 next to the backbone and are joined before fucb_layer
-        s0 = len(self.ops_meta)
-        cb = self._buf("cb192", N, h, w, 192)
-        g1 = self._buf("gauss1", N, h, w, 64)
-        o1 = self._buf("ob1", N, h, w, 64)
-        self.fork(1)
-        self.ir_block("gauss.0", g0, m.gauss_cb_layer[0], g1)
-        self.ir_block("gauss.1", g1, m.gauss_cb_layer[1], cb.slice(0, 64))
-        self.main()
-        self.fork(2)
-        self.ir_block("ob.0", o0, m.ob_cb_layer[0], o1)
-        self.ir_block("ob.1", o1, m.ob_cb_layer[1], cb.slice(64, 64))
-        self.main()
-        self._mark("priors_side", s0)
 
         # ---- backbone: MobileNetV2 features[0:18] (model_feature.py:62-69)
         s0 = len(self.ops_meta)
@@ -507,7 +548,32 @@ class Engine:
                 d.mean[i], d.stdv[i] = synth.IMAGENET_MEAN[i], synth.IMAGENET_STD[i]
             self._add(self.lib.uavsal_plan_add_stem, d, "plan_add_stem")
         tapsrc = {}
+        cb = g1 = o1 = None
         for i in range(1, 18):
+            if i == 5:
+                self._mark("backbone.0-4", s0)
+                # ---- gaussian / observed prior nets (model.py:349,352): they depend only on the caller's
+                #      priors and are needed at fucb_layer, so they run on lanes 1 and 2 beside the backbone.
+                #      Recorded HERE, not at the top of the plan: the host launches in recording order, and
+                #      with these 14 small launches (+ 4 event operations) in front of it the stem reached
+                #      the GPU ~100 us late on every call (rocprofv3 kernel trace, profiles/r2_step_timeline.md).
+                s0 = len(self.ops_meta)
+                cb = self._buf("cb192", N, h, w, 192)
+                g1 = self._buf("gauss1", N, h, w, 64)
+                o1 = self._buf("ob1", N, h, w, 64)
+                for lane, nm, src, dst, c, blocks, mid, sl in (
+                        (1, "gauss", "cb0_in", g0, 8, m.gauss_cb_layer, g1, 0),
+                        (2, "ob", "cb1_in", o0, 20, m.ob_cb_layer, o1, 64)):
+                    self.fork(lane)
+                    if self._dry:
+                        self._meta(kind="layout", name=nm + ".in", flops=0.0, bytes=8.0 * N * c * hw)
+                    else:
+                        self.layout(nm + ".in", getattr(self, src).data_ptr(), dst.ptr, N, c, hw, c, 1)
+                    self.ir_block(nm + ".0", dst, blocks[0], mid)
+                    self.ir_block(nm + ".1", mid, blocks[1], cb.slice(sl, 64))
+                    self.main()
+                self._mark("priors_side", s0)
+                s0 = len(self.ops_meta)
             blk = feats[i]
             ho, wo = (x.h - 1) // blk.stride + 1, (x.w - 1) // blk.stride + 1
             y = self._buf("f%d" % i, N, ho, wo, blk.cout)
@@ -516,7 +582,7 @@ class Engine:
             tapsrc[i] = y
         c3, c4, c5 = tapsrc[6], tapsrc[13], tapsrc[17]
         self.named.update(c3=c3, c4=c4, c5=c5)
-        self._mark("backbone", s0)
+        self._mark("backbone.5-17", s0)
 
         # ---- SRF-Net head (model.py:139-158)
         s0 = len(self.ops_meta)
@@ -665,10 +731,11 @@ class Engine:
             for c in range(self.n_seq):
                 for hist, dst, _ in outs:
                     last = hist.frames(c * Lq + Lq - 1, 1)
+                    nm = "%s%d" % (dst.replace("_", "."), c)           # state.out0, cstate.out0, ...
                     if self._dry:
-                        self._meta(kind="layout", name="state.out", flops=0.0, bytes=8.0 * 256 * hw)
+                        self._meta(kind="layout", name=nm, flops=0.0, bytes=8.0 * 256 * hw)
                     else:
-                        self.layout("state.out", last.ptr, getattr(self, dst).data_ptr() + 4 * c * 256 * hw, 1, 256, hw, 256, 0)
+                        self.layout(nm, last.ptr, getattr(self, dst).data_ptr() + 4 * c * 256 * hw, 1, 256, hw, 256, 0)
         # error guard: poisons what the caller will see if any kernel of this run set the error word
         self._meta(kind="guard", name="guard", flops=0.0, bytes=0.0)
         if not self._dry:
@@ -735,6 +802,42 @@ class Engine:
                 stage.data_ptr(), buf.ptr, self.n_seq, 256, self.h * self.w, 256, 1, 0)
             L.check(self.lib.uavsal_layout(C.byref(d), self._stream()), "uavsal_layout(state)")
 
+    def _bind_in_place(self, x, cb0, cb1, state, cstate, lstm):
+        """Point the plan at the caller's tensors and at freshly allocated outputs (no staging copies, no
+        clones).  Non-contiguous inputs are made contiguous first; everything bound is kept referenced until
+        the next call."""
+        dev = self.device
+        x = x.reshape(self.x_in.shape).contiguous()
+        cb0 = cb0.reshape(self.cb0_in.shape).contiguous()
+        cb1 = cb1.reshape(self.cb1_in.shape).contiguous()
+        self._patch("features.0", 1 if self.in_dtype == torch.uint8 else 0, x.data_ptr())
+        self._patch("gauss.in", 0, cb0.data_ptr())
+        self._patch("ob.in", 0, cb1.data_ptr())
+        out = torch.empty((self.N, self.h * self.w), dtype=torch.float32, device=dev)
+        self._patch("conv_out_st.pl", 1, out.data_ptr())
+        self._patch("guard", 0, out.data_ptr())
+        hold = [x, cb0, cb1, out]
+        st = None
+        if self.persistent:
+            self._stage_state_persistent(state, cstate)
+        else:
+            shape = self.state_in.shape
+            per = 4 * 256 * self.h * self.w
+            pairs = [("state", state, 1)] + ([("cstate", cstate, 2)] if lstm else [])
+            outs = []
+            for nm, t, gslot in pairs:
+                t = self.zero_state if t is None else t.reshape(shape).contiguous()
+                self._patch(nm + ".in", 0, t.data_ptr())
+                o = torch.empty(shape, dtype=torch.float32, device=dev)
+                for c in range(self.n_seq):
+                    self._patch("%s.out%d" % (nm, c), 1, o.data_ptr() + c * per)
+                self._patch("guard", gslot, o.data_ptr())
+                hold += [t, o]
+                outs.append(o)
+            st = (outs[0], outs[1]) if lstm else outs[0]
+        self._hold = hold
+        return out, st
+
     def stage_inputs(self, x, cb0, cb1, state, cstate=None):
         self.x_in.copy_(x.reshape(self.x_in.shape))
         self.cb0_in.copy_(cb0.reshape(self.cb0_in.shape))
@@ -753,20 +856,26 @@ class Engine:
     def run(self, x, cb0, cb1, state=None, taps: Optional[dict] = None, cstate=None):
         if x.dtype != self.in_dtype:
             raise RuntimeError("engine built for %s frames, got %s" % (self.in_dtype, x.dtype))
+        lstm = getattr(self.model, "rnn_type", "twa") == "lstm"
         with torch.cuda.device(self.device):
             self.check(wait=False)               # a previous asynchronous run that is over by now
-            self.stage_inputs(x, cb0, cb1, state, cstate)
+            if self.inplace:
+                out, st = self._bind_in_place(x, cb0, cb1, state, cstate, lstm)
+            else:
+                self.stage_inputs(x, cb0, cb1, state, cstate)
             self.launch()
             if self.sync_errors:
                 self.check(wait=True)
-            out = self.out.clone()
-            lstm = getattr(self.model, "rnn_type", "twa") == "lstm"
+            if not self.inplace:
+                out = self.out.clone()
+                if self.persistent:
+                    st = None
+                else:
+                    st = self.state_out.clone()
+                    if lstm:
+                        st = (st, self.cstate_out.clone())
             if self.persistent:          # opt-in aliasing: views of the resident state, overwritten by the next call
                 st = (self.h_view, self.c_view) if lstm else self.h_view
-            else:
-                st = self.state_out.clone()
-                if lstm:
-                    st = (st, self.cstate_out.clone())
             if taps is not None:
                 if not self.keep_taps:
                     raise RuntimeError("engine was built without taps")

@@ -167,10 +167,14 @@ class UAVSal(nn.Module):
         self.use_lanes = True           # independent branches on parallel streams / graph branches
         self.stream_k = True            # fp32 GEMMs: split K across workgroups when whole tiles leave CUs idle
         self.presplit = True            # f16x3: producers also write hi/lo fp16 shadows, GEMMs stage them by LDS-DMA
+        self.fuse_blocks = True         # features[1..7]: whole inverted-residual block in one launch (uavsal_fused_ir)
         # A device-side error (a stream-K hand-off that timed out) always NaN-fills the returned map and state.
-        # True: forward also waits for its own launches (one event wait) and raises before returning;
-        # False: fully asynchronous, the RuntimeError comes from the next forward / `check_errors()`.
-        self.sync_errors = True
+        # True: the call also waits for its own launches (one event wait) and raises before returning;
+        # False: fully asynchronous, the RuntimeError comes from the next call / `check_errors()`.
+        # None (default): `forward` -- the reference surface, whose caller reads the map right away
+        # (Demo_Test.py:87) -- waits; `forward_clips` -- the throughput surface -- does not: the wait costs the
+        # host/GPU overlap between calls, ~3 % of a 5.8 ms step (profiles/r2_step_timeline.md).
+        self.sync_errors = None
         # Opt-in persistent recurrent state (SURVEY.md 8(b) "Ownership", BASELINE configs[4]): the state stays
         # in the engine's NHWC buffer between calls; the returned state is a channels-last VIEW of that buffer
         # (valid until the next call overwrites it) and passing it back costs nothing.  Default False keeps the
@@ -242,7 +246,7 @@ class UAVSal(nn.Module):
             self._drop_engines()
         return super().train(mode)
 
-    def _engine(self, device, n_seq, seq_len, H, W, ctx_mode, taps=False, in_dtype=torch.float32):
+    def _engine(self, device, n_seq, seq_len, H, W, ctx_mode, taps=False, in_dtype=torch.float32, sync_default=True):
         from .engine import Engine
         if self.check_weight_versions:
             if self._wversion is None:
@@ -251,11 +255,11 @@ class UAVSal(nn.Module):
                 self._wversion = self._weights_version()
             elif self._weights_version() != self._wversion:      # param.data.copy_(...), an optimizer step, ...
                 self._drop_engines()
-                return self._engine(device, n_seq, seq_len, H, W, ctx_mode, taps, in_dtype)
+                return self._engine(device, n_seq, seq_len, H, W, ctx_mode, taps, in_dtype, sync_default)
         key = (str(device), n_seq, seq_len, H, W, self.time_dims if ctx_mode == "tile" else seq_len,
                ctx_mode, self.precision, bool(taps), in_dtype, bool(self.use_graph), self.rnn_type, self.fuse_dw, bool(self.use_lanes),
                bool(self.stream_k), bool(self.persistent_state), tuple(getattr(self, "_sk_debug", (0, 0))),
-               bool(self.presplit))
+               bool(self.presplit), bool(self.fuse_blocks))
         eng = self._engines.get(key)
         if eng is None:
             while len(self._engines) >= max(1, int(self.max_engines)):
@@ -269,7 +273,7 @@ class UAVSal(nn.Module):
             self._engines[key] = eng
         else:
             self._engines.move_to_end(key)
-        eng.sync_errors = bool(self.sync_errors)
+        eng.sync_errors = sync_default if self.sync_errors is None else bool(self.sync_errors)
         return eng
 
     def _check_common(self, x):
@@ -325,7 +329,7 @@ class UAVSal(nn.Module):
         C, T, _, H, W = x.shape
         if T < 2:
             raise RuntimeError("each clip needs at least 2 frames (reference teConv_sub, model.py:194)")
-        eng = self._engine(x.device, C, T, H, W, "clip", taps is not None, x.dtype)
+        eng = self._engine(x.device, C, T, H, W, "clip", taps is not None, x.dtype, sync_default=False)
         h, w = eng.h, eng.w
         self._check_cb([cb[0].reshape(C * T, *cb[0].shape[2:]), cb[1].reshape(C * T, *cb[1].shape[2:])], C * T, h, w)
         cst = None

@@ -182,6 +182,39 @@ def dw3x3(x, weight, scale, bias, stride=1, dilation=1, act=L.ACT_RELU6, out=Non
     return sp if split_out else out
 
 
+def fused_ir(x, w1, bn1, wd, bnd, w2, bn2, stride=1, residual=False):
+    """One inverted-residual block as a single launch (uavsal_fused_ir).  `x` NHWC; `w1` [hid,Cin,1,1] or None
+    (no expand conv); `wd` [hid,1,3,3]; `w2` [Cout,hid,1,1]; bn* = (scale, bias) folded BatchNorms."""
+    lib = L.load()
+    ip, ldi, n, h, w, cin = _nhwc_view(x)
+    hid, cout = wd.shape[0], w2.shape[0]
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    out = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x.device)
+    dev = x.device
+    keep = []
+
+    def up(t):
+        t = t.detach().float().contiguous().to(dev)
+        keep.append(t)
+        return t.data_ptr()
+    d = L.FusedIrDesc()
+    d.inp, d.ldi = ip, ldi
+    if w1 is not None:
+        d.w1 = up(w1.reshape(hid, cin).t())
+        d.scale1, d.bias1 = up(bn1[0]), up(bn1[1])
+    d.wd, d.scale_d, d.bias_d = up(P.pack_dw_weight(wd)), up(bnd[0]), up(bnd[1])
+    d.w2, d.scale2, d.bias2 = up(w2.reshape(cout, hid).t()), up(bn2[0]), up(bn2[1])
+    if residual:
+        d.res, d.ldr = ip, ldi
+    d.out, d.ldo = out.data_ptr(), cout
+    d.n_img, d.H, d.W, d.Cin, d.hidden, d.Cout, d.stride = n, h, w, cin, hid, cout, stride
+    if not int(lib.uavsal_fused_ir_supported(C.byref(d))):
+        raise RuntimeError("no fused inverted-residual instance for (Cin, hidden, Cout, stride) = %s" % ((cin, hid, cout, stride),))
+    L.check(lib.uavsal_fused_ir(C.byref(d), _stream(x)), "uavsal_fused_ir")
+    torch.cuda.current_stream(dev).synchronize()
+    return out
+
+
 def stem_conv(x_nchw, weight, scale, bias):
     lib = L.load()
     n, _, H, W = x_nchw.shape

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define UAVSAL_ABI_VERSION 10
+#define UAVSAL_ABI_VERSION 11
 
 /* argument errors */
 #define UAVSAL_EINVAL   (-1)  /* null pointer / non-positive size */
@@ -196,6 +196,30 @@ int uavsal_dw3x3(const uavsal_dw_desc* d, uavsal_stream_t stream);
 int uavsal_dw_variant(const uavsal_dw_desc* d);
 
 /*
+ * Fused inverted-residual block: pw-expand + BN + ReLU6 -> depthwise 3x3 (stride 1 / 2, pad 1) + BN + ReLU6 ->
+ * pw-linear + BN [+ x], ONE launch, the 6x-expanded tensors stay in LDS.  Replaces a whole torchvision
+ * InvertedResidual / dwBlock (model.py:74-103, model_feature.py:62-66) where the block is bandwidth-bound:
+ * instances exist for (Cin, hidden, Cout, stride) of MobileNetV2 features[1..7] -- (32,32,16,1) with w1 == NULL
+ * (t = 1: no expand conv), (16,96,24,2), (24,144,24,1), (24,144,32,2), (32,192,32,1), (32,192,64,2);
+ * uavsal_fused_ir_supported tells.  Exact fp32 FMA arithmetic whatever the GEMM precision of the plan.
+ * Weights (host-packed, fp32): w1 [Cin][hidden] (= conv weight transposed), wd [9][hidden] tap-major as in
+ * uavsal_dw_desc, w2 [hidden][Cout]; scale* / bias* are the folded BatchNorms.  res (or NULL) is the block
+ * input for the residual connection (stride 1, Cin == Cout): out = bn3(...) + res.
+ */
+typedef struct uavsal_fused_ir_desc {
+    const float* in;   int32_t ldi;
+    const float* w1;   const float* scale1;  const float* bias1;      /* NULL for a block without expand conv */
+    const float* wd;   const float* scale_d; const float* bias_d;
+    const float* w2;   const float* scale2;  const float* bias2;
+    const float* res;  int32_t ldr;
+    float*       out;  int32_t ldo;
+    int32_t n_img, H, W, Cin, hidden, Cout, stride;
+} uavsal_fused_ir_desc;
+
+int uavsal_fused_ir(const uavsal_fused_ir_desc* d, uavsal_stream_t stream);
+int uavsal_fused_ir_supported(const uavsal_fused_ir_desc* d);     /* 1 / 0; no launch */
+
+/*
  * Stem: dense 3x3 stride-2 pad-1 convolution 3 -> 32 + BatchNorm + ReLU6 reading the
  * caller's NCHW fp32 frames and writing NHWC.  Replaces torchvision
  * mobilenet_v2().features[0] as run by ReMobileNetV2.forward (model_feature.py:63).
@@ -322,6 +346,7 @@ int uavsal_plan_add_tdiff(uavsal_plan* p, const uavsal_tdiff_desc* d);
 int uavsal_plan_add_tsum(uavsal_plan* p, const uavsal_tsum_desc* d);
 int uavsal_plan_add_layout(uavsal_plan* p, const uavsal_layout_desc* d);
 int uavsal_plan_add_copy(uavsal_plan* p, const uavsal_copy_desc* d);
+int uavsal_plan_add_fused_ir(uavsal_plan* p, const uavsal_fused_ir_desc* d);
 /* The plan owns one device error word (for uavsal_conv_desc.err of its convs) and a host mirror of it.
  * add_guard records a uavsal_guard over up to three output buffers with those words filled in. */
 int32_t* uavsal_plan_error_word(uavsal_plan* p);
@@ -331,6 +356,13 @@ int uavsal_plan_add_guard(uavsal_plan* p, float* b0, int64_t n0, float* b1, int6
  * once: the words are cleared; the caller re-zeroes its stream-K workspaces).  wait != 0 blocks until
  * the run has finished. */
 int uavsal_plan_status(uavsal_plan* p, int wait);
+/* Re-point one tensor of a recorded op at the caller's buffer, so that a forward reads the caller's frames /
+ * priors / state in place and writes the map / state straight into freshly allocated outputs (no staging
+ * copies, no clones; SURVEY.md 8(b): inputs are not modified, outputs are owned by the caller).
+ * `slot`: conv 0 = a, 1 = out;  stem 0 = in (fp32), 1 = in_u8 (the other is cleared);  layout 0 = in, 1 = out;
+ * guard 0..2 = buf[slot].  Shapes, strides and every other field stay as recorded.  Not available once the
+ * plan has been captured into a graph (UAVSAL_ESTATE): a graph replays fixed addresses. */
+int uavsal_plan_patch_ptr(uavsal_plan* p, int op, int slot, void* ptr);
 /* Parallel branches: ops are recorded on the current lane (0 = the caller's stream, 1..7 = private
  * streams).  fork(l): lane l starts after everything recorded on lane 0 so far; join(l): lane 0 waits
  * for lane l.  Every forked lane must be joined before the plan ends.  A captured plan keeps the
@@ -352,7 +384,7 @@ int uavsal_plan_graph_launch(uavsal_plan* p, uavsal_stream_t stream);
 int uavsal_plan_time(uavsal_plan* p, int first, int last, int iters, uavsal_stream_t stream, float* ms);
 
 int uavsal_abi_version(void);
-int uavsal_sizeof_desc(int which); /* 0 conv,1 dw,2 stem,3 bilinear,4 tdiff,5 tsum,6 layout,7 post,8 guard,9 copy */
+int uavsal_sizeof_desc(int which); /* 0 conv,1 dw,2 stem,3 bilinear,4 tdiff,5 tsum,6 layout,7 post,8 guard,9 copy,10 fused_ir */
 const char* uavsal_build_info(void);
 
 #ifdef __cplusplus

@@ -202,9 +202,17 @@ def test_lost_streamk_piece_raises_and_poisons(hip_model):
         assert torch.isnan(out).all() and torch.isnan(st[0]).all()
         with pytest.raises(RuntimeError, match="stream-K"):
             hip_model.check_errors()          # ... and the error is reported at the next check
+        # forward_clips (throughput surface) is asynchronous by default: poisoned result, error at the next check
+        hip_model.sync_errors = None
+        xc = args[0].view(1, 4, 3, 96, 160)
+        oc, sc = hip_model.forward_clips(xc, [args[1][0].view(1, 4, 8, 12, 20), args[1][1].view(1, 4, 20, 12, 20)], None)
+        torch.cuda.synchronize()
+        assert torch.isnan(oc).all() and torch.isnan(sc).all()
+        with pytest.raises(RuntimeError, match="stream-K"):
+            hip_model.check_errors()
     finally:
         hip_model._sk_debug = (0, 0)
-        hip_model.sync_errors = True
+        hip_model.sync_errors = None
     again, _ = hip_model(*args)               # workspaces were re-zeroed: the healthy plan still works
     assert torch.equal(again, good)
     assert all(e.streamk_clean() for e in hip_model._engines.values())

@@ -435,3 +435,44 @@ def test_bilinear_split_output(ops):
     x = nhwc(rnd((3, 64, 12, 20), 71, 3.0))
     out, sp = ops.bilinear_ac(x, 45, 80, split_out=True)
     assert (ops.merge_shadow(sp) - out).abs().max().item() <= 3.0 * 2 ** -20
+
+
+# ---- fused inverted-residual block (uavsal_fused_ir): MobileNetV2 features[1..7] in one launch each --------
+FUSED_CASES = [
+    # n, h, w, cin, hidden, cout, stride, residual
+    (2, 20, 36, 32, 32, 16, 1, False),      # features.1 (no expand conv)
+    (2, 21, 35, 16, 96, 24, 2, False),      # features.2, odd sizes: partial patches on both edges
+    (1, 19, 27, 24, 144, 24, 1, True),      # features.3 (residual)
+    (2, 18, 32, 24, 144, 32, 2, False),     # features.4
+    (1, 45, 80, 32, 192, 32, 1, True),      # features.5 / .6 at the 360x640 map size
+    (3, 9, 13, 32, 192, 64, 2, False),      # features.7
+    (1, 5, 3, 16, 96, 24, 2, False),        # smaller than one patch
+]
+
+
+@pytest.mark.parametrize("case", FUSED_CASES)
+def test_fused_inverted_residual(ops, case):
+    n, h, w, cin, hid, cout, stride, res = case
+    x = rnd((n, cin, h, w), 101, 2.0)
+    bn = lambda c, s: (rnd((c,), s) * 0.5 + 1.0, rnd((c,), s + 1))
+    w1 = rnd((hid, cin, 1, 1), 102, 1.0 / np.sqrt(cin)) if hid != cin or cin != 32 else None
+    wd = rnd((hid, 1, 3, 3), 103, 0.4)
+    w2 = rnd((cout, hid, 1, 1), 104, 1.0 / np.sqrt(hid))
+    b1, bd, b2 = bn(hid, 105), bn(hid, 107), bn(cout, 109)
+    aff = lambda y, b: y * b[0].view(1, -1, 1, 1) + b[1].view(1, -1, 1, 1)
+    e = x if w1 is None else torch.clamp(aff(F.conv2d(x, w1), b1), 0, 6)
+    dd = torch.clamp(aff(F.conv2d(e, wd, stride=stride, padding=1, groups=hid), bd), 0, 6)
+    ref = aff(F.conv2d(dd, w2), b2)
+    if res:
+        ref = ref + x
+    got = ops.fused_ir(nhwc(x), w1, b1, wd, bd, w2, b2, stride=stride, residual=res)
+    assert tuple(got.shape) == (n, ref.shape[2], ref.shape[3], cout)
+    err = (nchw(got) - ref).abs().max().item()
+    assert err <= 2e-5 * max(1.0, ref.abs().max().item()), (case, err)
+
+
+def test_fused_inverted_residual_rejects_other_shapes(ops):
+    x = nhwc(rnd((1, 64, 9, 13), 111))
+    with pytest.raises(RuntimeError):
+        ops.fused_ir(x, rnd((384, 64, 1, 1), 1), (torch.ones(384), torch.zeros(384)), rnd((384, 1, 3, 3), 2),
+                     (torch.ones(384), torch.zeros(384)), rnd((64, 384, 1, 1), 3), (torch.ones(64), torch.zeros(64)))
