@@ -153,7 +153,8 @@ def kernel_rooflines(eng, prec, iters=5):
         if os.environ.get("UAVSAL_BENCH_OPS"):
             print("[op %3d] %-28s %-8s %9.1f us %8.1f GB/s %8.2f TFLOP/s" % (
                 i, m["name"], key[-22:], ms * 1e3, m["bytes"] / ms / 1e6, m["flops"] / ms / 1e9), file=sys.stderr)
-        g = groups.setdefault(key, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0, "kind": m["kind"]})
+        g = groups.setdefault(key, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0, "kind": m["kind"], "unfused_bytes": 0.0})
+        g["unfused_bytes"] += m.get("unfused_bytes", 0.0)
         g["ms"] += ms
         g["flops"] += m["flops"]
         g["bytes"] += m["bytes"]
@@ -179,15 +180,17 @@ def roofline_obj(name, g, prec):
 
 
 def depthwise_family(groups):
-    """every depthwise layer of the forward (34 at 360x640), algorithmic bytes
-    N*C*(HiWi+HoWo)*4 + 44*C summed over the layers / their summed kernel time, against the HBM peak.
-    The per-instance split is kept beside the family figure."""
+    """every stand-alone depthwise launch of the forward, algorithmic bytes
+    N*C*(HiWi+HoWo)*4 + 44*C summed over the layers / their summed kernel time, against the HBM peak; the
+    per-instance split is kept beside the family figure.  Depthwise layers that run inside a fused
+    inverted-residual launch (features[1..7]) have no launch of their own: they are reported by
+    `roofline_fused` (fused-floor bytes / time), as 8(d) prescribes."""
     dw = {k: g for k, g in groups.items() if g["kind"] == "dw"}
     if not dw:
         return None
     byts = sum(g["bytes"] for g in dw.values())
     ms = sum(g["ms"] for g in dw.values())
-    fam = {"kernel": "depthwise 3x3 family (all dw layers of the forward)", "bound": "hbm",
+    fam = {"kernel": "depthwise 3x3 family (all stand-alone dw launches of the forward)", "bound": "hbm",
            "achieved": round(byts / ms / 1e6, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
            "frac": round(byts / ms / 1e6 / PEAK_HBM_GBS, 4), "traffic": None,
            "launches_per_step": sum(g["launches"] for g in dw.values()),
@@ -196,6 +199,22 @@ def depthwise_family(groups):
         fam["instances"][k] = {"launches": g["launches"], "ms": round(g["ms"], 4), "alg_mb": round(g["bytes"] / 1e6, 3),
                                "frac": round(g["bytes"] / g["ms"] / 1e6 / PEAK_HBM_GBS, 4)}
     return fam
+
+
+def fused_family(groups):
+    """Fused inverted-residual launches: fused-floor bytes (block input + output [+ residual read]) / time."""
+    fu = {k: g for k, g in groups.items() if g["kind"] == "fused_ir"}
+    if not fu:
+        return None
+    byts = sum(g["bytes"] for g in fu.values())
+    ms = sum(g["ms"] for g in fu.values())
+    fl = sum(g["flops"] for g in fu.values())
+    return {"kernel": "fused_ir_kernel (features[1..7], expand + depthwise + project per launch)", "bound": "hbm",
+            "achieved": round(byts / ms / 1e6, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": round(byts / ms / 1e6 / PEAK_HBM_GBS, 4), "traffic": None,
+            "launches_per_step": sum(g["launches"] for g in fu.values()), "fused_floor_mb_per_step": round(byts / 1e6, 3),
+            "kernel_ms_per_step": round(ms, 4), "tflops_fp32": round(fl / ms / 1e9, 2),
+            "note": "unfused, the same seven blocks move %.0f MB per step" % (sum(g.get("unfused_bytes", 0.0) for g in fu.values()) / 1e6)}
 
 
 def timed_steps(fn, steps, warmup, distributed, device):
@@ -332,6 +351,10 @@ def main():
                 if big in fam["instances"]:
                     fam["instances"][big]["traffic"], _ = measured_traffic(big, C, T, H, W, args.prec)
                 result["roofline_dw"] = fam
+            fus = fused_family(groups)
+            if fus:
+                fus["share_of_kernel_time"] = round(fus["kernel_ms_per_step"] / tot, 3)
+                result["roofline_fused"] = fus
             result["kernel_time_ms"] = {k: round(v["ms"], 4) for k, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])}
             result["stage_time_ms"] = {k: round(eng.time_ops(a, b, 5), 4) for k, (a, b) in eng.stage_ranges.items()}
         if not args.no_cpu_baseline:

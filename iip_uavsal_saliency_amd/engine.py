@@ -417,7 +417,9 @@ class Engine:
         self._meta(kind="fused_ir", name=name, kernel="fused_ir_kernel<%d, %d, %d, %d>" % (x.c, blk.hidden, out.c, blk.stride),
                    flops=2.0 * x.n * ((x.h * x.w * x.c * blk.hidden if blk.expand_ratio != 1 else 0)
                                       + ho * wo * blk.hidden * (9 + out.c)),
-                   bytes=4.0 * x.n * (x.h * x.w * x.c + ho * wo * out.c * (2 if blk.use_res_connect else 1)))
+                   bytes=4.0 * x.n * (x.h * x.w * x.c + ho * wo * out.c * (2 if blk.use_res_connect else 1)),
+                   unfused_bytes=4.0 * x.n * (x.h * x.w * (x.c + (2 * blk.hidden if blk.expand_ratio != 1 else 0))
+                                              + ho * wo * (2 * blk.hidden + out.c)))
         if out.key is not None:
             self._no_shadow.add(out.key)            # this kernel does not write split shadows
         if self._dry:
