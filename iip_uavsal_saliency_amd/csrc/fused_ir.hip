@@ -21,12 +21,6 @@
 // bandwidth-bound (4 GMAC per clip in total).
 #include "common.h"
 
-#ifdef UAVSAL_FUSED_FAKEW          /* timing experiment only: no weight loads */
-#define UAVSAL_FAKEW(x) (0.001f * (float)(lane + s))
-#else
-#define UAVSAL_FAKEW(x) (x)
-#endif
-
 namespace {
 
 struct FusedK {
@@ -97,7 +91,7 @@ __global__ __launch_bounds__(256) void fused_ir_kernel(const FusedK p) {
             for (int ct = 0; ct < NCTE; ++ct) {
                 const int c = c0 + ct * 16 + l15;
 #pragma unroll
-                for (int s = 0; s < KE; ++s) w1f[ct][s] = UAVSAL_FAKEW(p.w1[(size_t)(4 * s + lq) * HID + c]);
+                for (int s = 0; s < KE; ++s) w1f[ct][s] = p.w1[(size_t)(4 * s + lq) * HID + c];
                 s1f[ct] = p.s1[c]; b1f[ct] = p.b1[c];
             }
         }
@@ -106,7 +100,7 @@ __global__ __launch_bounds__(256) void fused_ir_kernel(const FusedK p) {
         for (int ct = 0; ct < NCT; ++ct) {
             const int co = ct * 16 + l15;
 #pragma unroll
-            for (int s = 0; s < KP; ++s) w2f[ct][s] = co < COUT ? UAVSAL_FAKEW(p.w2[(size_t)(c0 + 4 * s + lq) * COUT + co]) : 0.f;
+            for (int s = 0; s < KP; ++s) w2f[ct][s] = co < COUT ? p.w2[(size_t)(c0 + 4 * s + lq) * COUT + co] : 0.f;
         }
         // depthwise: lane = channel (wave % NJOB) * 16 + l15 of the chunk, pixel part (wave / NJOB, lq)
         const bool dw_on = wave < NJOB * NPART;
