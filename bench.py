@@ -36,11 +36,11 @@ PEAK_TFLOPS = {"f32": 157.3, "f16x3": 2500.0 / 3, "bf16x3": 2500.0 / 3, "bf16": 
 PEAK_HBM_GBS = 8000.0
 DTYPE_NAME = {"f32": "f32", "f16x3": "f32 (3x f16 split MFMA, f32 accumulate)",
               "bf16x3": "f32 (3x bf16 split MFMA, f32 accumulate)", "bf16": "bf16"}
-TILE_NAME = {1: "128x128", 2: "128x64", 3: "128x32", 4: "64x64"}
+TILE_NAME = {1: "128x128", 2: "128x64", 3: "128x32", 4: "64x64", 5: "128x256", 6: "256x256", 7: "256x128"}
 PREC_ID = {"f32": 0, "bf16x3": 1, "bf16": 2, "f16x3": 3}
 # template arguments of the kernel instance each (precision, tile) launches, as rocprofv3 prints them
 F32_INST = {1: "2, 2, 2, 2, %d, 3, 1, false", 2: "4, 1, 1, 2, %d, 4, 1, false", 3: "4, 1, 1, 1, %d, 4, 1, false",
-            4: "2, 2, 1, 1, %d, 3, 4, false"}
+            4: "2, 2, 1, 1, %d, 3, 4, false", 7: "4, 2, 2, 2, %d, 3, 1, false"}
 F32_SK_INST = {1: "2, 2, 2, 2, %d, 3, 1, true", 3: "4, 1, 1, 1, %d, 4, 1, true", 4: "2, 2, 1, 1, %d, 3, 2, true"}   # stream-K
 H16_INST = {1: "%d, 2, 2, 2, 2, %d", 2: "%d, 4, 1, 1, 2, %d", 3: "%d, 4, 1, 1, 1, %d", 4: "%d, 2, 2, 1, 1, %d",
             5: "%d, 2, 4, 2, 2, %d", 6: "%d, 2, 4, 4, 2, %d"}

@@ -29,6 +29,7 @@
 //   * blockIdx is remapped so that each XCD (private L2) owns a contiguous range of
 //     (M tile, N tile) pairs: the N tiles that re-read one activation tile run on the
 //     same L2.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -635,20 +636,25 @@ void conv_gemm_kernel(const ConvK p) {
 // piece LAST, adds the published pieces in a fixed order and runs the epilogue -- nobody waits
 // on work that has not been started, and the summation order is fixed by the grid.
 template <int WAVES_M, int WAVES_N, int WM, int WN, int TAPS, int S, int NKP, bool SK = false>
-__global__ __launch_bounds__(256, SK ? 2 : ((WM * WN >= 4) ? 3 : 4)) void conv_gemm_f32_dma_kernel(const ConvK p) {
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, WAVES_M * WAVES_N == 8 ? 4 : (SK ? 2 : ((WM * WN >= 4) ? 3 : 4)))
+void conv_gemm_f32_dma_kernel(const ConvK p) {
     constexpr int BM = WAVES_M * WM * 32;
     constexpr int BN = WAVES_N * WN * 32;
     constexpr int KT = 16;                       // one 64-byte panel row; a stage holds NKP panels
-    constexpr int NT = 256;
-    constexpr int A_IT = (BM * 4) / 256;
-    constexpr int B_IT = (BN * 4 + 255) / 256;
+    constexpr int NW = WAVES_M * WAVES_N;        // 4 waves, or 8 for the 256 x 128 tile (whole-tile path only)
+    constexpr int NT = NW * 64;
+    constexpr int RPI = NT / 4;                  // panel rows one DMA iteration of the workgroup covers
+    constexpr int A_IT = (BM * 4) / NT;
+    constexpr int B_IT = (BN * 4 + NT - 1) / NT;
+    constexpr int BWR = (BN / 16 < NW) ? BN / 16 : NW;   // waves with distinct B rows in one iteration
     constexpr int LPT = NKP * (A_IT + B_IT);     // DMA instructions per thread per stage
     constexpr int D = S - 1;                     // prefetch distance in stages
     constexpr int APAN = BM * 64;
     constexpr int BPAN = BN * 64;
     constexpr int PANEL = APAN + BPAN;
     constexpr int STAGE = NKP * PANEL;
-    static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+    static_assert(NW == 4 || (NW == 8 && !SK), "4 waves per workgroup (8 for the whole-tile 256 x 128 instance)");
+    static_assert((BM * 4) % NT == 0, "A tile must divide over the workgroup");
     static_assert(BN == 32 || BN == 64 || BN == 128, "B tile shape");
     static_assert(LPT * (D - 1) < 64, "vmcnt immediate");
     static_assert(STAGE >= 32 * BN * 4, "epilogue staging must fit one ring stage");
@@ -664,7 +670,7 @@ __global__ __launch_bounds__(256, SK ? 2 : ((WM * WN >= 4) ? 3 : 4)) void conv_g
     const int tile_end = walk.end, tile_step = walk.stride;
     int m0 = 0, n0 = 0;
 
-    // per-thread DMA coordinates: row (tid>>2) + it*64 of the tile, physical chunk tid&3
+    // per-thread DMA coordinates: row (tid>>2) + it*RPI of the tile, physical chunk tid&3
     const int pc = tid & 3;
     long long a_base[A_IT];          // element offset of the row's centre pixel
     int a_taps[A_IT], a_lc[A_IT];    // 3x3: bit t set = tap t of this row lies inside the image
@@ -678,7 +684,7 @@ __global__ __launch_bounds__(256, SK ? 2 : ((WM * WN >= 4) ? 3 : 4)) void conv_g
         n0 = tile_n * BN;
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
-            const int row = (tid >> 2) + it * 64;
+            const int row = (tid >> 2) + it * RPI;
             a_lc[it] = pc ^ ((row >> 2) & 3);
             const int m = m0 + row;
             a_ok[it] = m < p.M;
@@ -704,8 +710,8 @@ __global__ __launch_bounds__(256, SK ? 2 : ((WM * WN >= 4) ? 3 : 4)) void conv_g
         }
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
-            const int wrow = (BN >= 64) ? (tid >> 6) * 16 : ((tid >> 6) & 1) * 16;
-            const int row = wrow + ((tid & 63) >> 2) + it * 64;
+            const int wrow = ((tid >> 6) % BWR) * 16;
+            const int row = wrow + ((tid & 63) >> 2) + it * RPI;
             b_lc[it] = pc ^ ((row >> 2) & 3);
         }
     };
@@ -737,20 +743,20 @@ __global__ __launch_bounds__(256, SK ? 2 : ((WM * WN >= 4) ? 3 : 4)) void conv_g
                 const long long off = a_base[it] + tap_off;
                 const int kk = ci0 + a_lc[it] * 4;
                 const float* src = (ok && kk < p.Cin) ? (p.a + off + kk) : zero;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + (it * 64 + wave_u * 16) * 64), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + (it * RPI + wave_u * 16) * 64), 16, 0, 0);
             }
 #pragma unroll
             for (int it = 0; it < B_IT; ++it) {
                 // BN = 32: the panel has only 32 rows; waves 2,3 re-request the rows of waves 0,1
                 // (identical bytes to identical addresses) so that EVERY wave issues exactly LPT
                 // requests per stage -- the counted s_waitcnt vmcnt below depends on it.
-                const int wrow = (BN >= 64) ? wave_u * 16 : (wave_u & 1) * 16;
-                const int row = wrow + ((tid & 63) >> 2) + it * 64;
+                const int wrow = (wave_u % BWR) * 16;
+                const int row = wrow + ((tid & 63) >> 2) + it * RPI;
                 const int nn = n0 + row;
                 const float* src = zero;
                 if (kin && row < BN && nn < p.Npad)
                     src = reinterpret_cast<const float*>(p.w) + (size_t)nn * p.Kpad + (size_t)kt * KT + b_lc[it] * 4;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Bs + (it * 64 + wrow) * 64), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Bs + (it * RPI + wrow) * 64), 16, 0, 0);
             }
         }
     };
@@ -1307,25 +1313,26 @@ typedef SkCfg<4, 1, 1, 1, 4, 1> SkThin;     // 128 x 32 (Cout <= 32: the 1536 ->
 
 template <int WAVES_M, int WAVES_N, int WM, int WN, int S, int NKP>
 int launch_f32_dma(const ConvK& k0, int taps, hipStream_t stream) {
-    constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32;
+    constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32, NT = WAVES_M * WAVES_N * 64;
     constexpr int SMEM = S * NKP * (BM + BN) * 64;
     ConvK k = k0;
     const int tiles_m = (k.M + BM - 1) / BM;
     k.tiles_n = (k.Cout + BN - 1) / BN;
     k.nblk = tiles_m * k.tiles_n;
     if (taps == 1) {
-        static const int cap = resident_grid(conv_gemm_f32_dma_kernel<WAVES_M, WAVES_N, WM, WN, 1, S, NKP>, SMEM);
+        static const int cap = resident_grid(conv_gemm_f32_dma_kernel<WAVES_M, WAVES_N, WM, WN, 1, S, NKP>, SMEM, NT);
         const int grid = k.nblk < cap ? k.nblk : cap;
-        hipLaunchKernelGGL((conv_gemm_f32_dma_kernel<WAVES_M, WAVES_N, WM, WN, 1, S, NKP>), dim3(grid), dim3(256), SMEM, stream, k);
+        hipLaunchKernelGGL((conv_gemm_f32_dma_kernel<WAVES_M, WAVES_N, WM, WN, 1, S, NKP>), dim3(grid), dim3(NT), SMEM, stream, k);
     } else {
-        static const int cap = resident_grid(conv_gemm_f32_dma_kernel<WAVES_M, WAVES_N, WM, WN, 9, S, NKP>, SMEM);
+        static const int cap = resident_grid(conv_gemm_f32_dma_kernel<WAVES_M, WAVES_N, WM, WN, 9, S, NKP>, SMEM, NT);
         const int grid = k.nblk < cap ? k.nblk : cap;
-        hipLaunchKernelGGL((conv_gemm_f32_dma_kernel<WAVES_M, WAVES_N, WM, WN, 9, S, NKP>), dim3(grid), dim3(256), SMEM, stream, k);
+        hipLaunchKernelGGL((conv_gemm_f32_dma_kernel<WAVES_M, WAVES_N, WM, WN, 9, S, NKP>), dim3(grid), dim3(NT), SMEM, stream, k);
     }
     return uavsal_launch_status();
 }
 
 int launch_f32(const ConvK& k, int taps, int tile, hipStream_t stream) {
+    if (tile == 7) return launch_f32_dma<4, 2, 2, 2, 3, 1>(k, taps, stream);     // 256 x 128 on 8 waves, 3 x 24 KB ring
     switch (tile) {
         case 5:
         case 6:
@@ -1430,6 +1437,12 @@ int pick_tile(long long M, int Cout, int prec) {
         if (((M + 255) / 256) * (Cout / 256) >= 512) return 6;
         if (((M + 127) / 128) * (Cout / 256) >= 192) return 5;
     }
+    // fp32 256 x 128 on 8 waves (tile 7; a quarter fewer operand bytes per FLOP than 128 x 128) is NOT picked
+    // automatically.  Isolated (profiles/r2_f32_tile7_probe.log) the 256 -> 1536 expand gains 3 % at 8 frames and
+    // 10 % at 64, the 3x3 448 -> 256 conv 7 %; inside the forward the same build is 0.6 % (1 clip) and 1.1 % (8 clips)
+    // SLOWER end to end, two same-box runs each (1444 / 1671 vs 1453 / 1691 frames/s).  UAVSAL_TILE7=1 opts in.
+    static const bool tile7_on = [] { const char* e = getenv("UAVSAL_TILE7"); return e && e[0] == '1'; }();
+    if (tile7_on && prec == UAVSAL_PREC_F32 && Cout % 128 == 0 && ((M + 255) / 256) * (Cout / 128) >= 768) return 7;
     // Among the tiles that give >= 256 blocks: least padded-N work, the narrower tiles charged 5 / 35 % for
     // their lower efficiency (Cout = 144: 128x64 27.8 us vs 128x128 33.2; 576: 42.2 vs 46.5; 96: 42.2 with
     // 128x128 vs 50.3, same padding; 24: 128x32 19.9 vs 31.1 -- profiles/r1_gemm_probe_v3.log).
@@ -1451,8 +1464,9 @@ int pick_tile(long long M, int Cout, int prec) {
 }  // namespace
 
 static int effective_tile(const uavsal_conv_desc* d) {
-    int tile = (d->tile >= 1 && d->tile <= 6) ? d->tile
+    int tile = (d->tile >= 1 && d->tile <= 7) ? d->tile
                                              : pick_tile((long long)d->H * d->W * d->n_img, d->Cout, d->prec);
+    if (tile == 7 && (d->prec != UAVSAL_PREC_F32 || d->dw_w9c)) tile = 1;     // 256 x 128 exists for the fp32 LDS-DMA kernel
     if (tile == 6) {   // the 256 x 256 tile only carries the vector epilogue
         const bool vec = d->epi == UAVSAL_EPI_AFFINE && d->act != UAVSAL_ACT_SIGMOID && !(d->ldc & 3) &&
                          !(d->Cout & 3) && uavsal_aligned16(d->out) &&

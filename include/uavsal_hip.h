@@ -117,7 +117,7 @@ typedef struct uavsal_conv_desc {
     int32_t Cin, Cout, taps;     /* taps: 1 or 9 */
     int32_t prec, act, epi;
     int32_t tile;                /* 0 = auto; else 1: 128x128, 2: 128x64, 3: 128x32, 4: 64x64, 5: 128x256, 6: 256x256 (split
-                                  * 16-bit precisions; others run them as 1) block tile */
+                                  * 16-bit precisions; others run them as 1), 7: 256x128 on 8 waves (F32; others as 1) */
     float*       out2;   int32_t ld2;                 /* EPI_LSTM only: c_t (image stride = o_img_stride) */
     /* Fused depthwise producer (taps == 1, EPI_AFFINE): when dw_w9c != NULL, `a` is the EXPANDED tensor E
      * [n_img, dw_Hin, dw_Win, Cin] of an inverted-residual block and the GEMM's A operand is computed on the
@@ -160,7 +160,7 @@ typedef struct uavsal_conv_desc {
 } uavsal_conv_desc;
 
 int uavsal_conv_gemm(const uavsal_conv_desc* d, uavsal_stream_t stream);
-/* block tile `uavsal_conv_gemm` will use for this descriptor (1..6, see `tile`); no launch */
+/* block tile `uavsal_conv_gemm` will use for this descriptor (1..7, see `tile`); no launch */
 int uavsal_conv_tile(const uavsal_conv_desc* d);
 /* 1 when `uavsal_conv_gemm` will take the pre-split LDS-DMA path for this descriptor (a_split set, shape
  * eligible) and therefore expects `w` in the 'f16x3i' packing, else 0; no launch */

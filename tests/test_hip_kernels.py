@@ -79,7 +79,7 @@ def test_conv1x1(ops, prec, case):
     assert err <= TOL[prec] * 4.0, (case, prec, err)
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("prec", ["f32", "f16x3", "bf16x3"])
 def test_conv1x1_all_tiles(ops, prec, tile):
     n, h, w, cin, cout = 2, 11, 13, 64, 160      # M = 286: ragged against every tile height
@@ -89,6 +89,25 @@ def test_conv1x1_all_tiles(ops, prec, tile):
     got = ops.conv_gemm(nhwc(x), wt, None, None, prec=prec, tile=tile)
     err = (nchw(got) - ref).abs().max().item()
     assert err <= TOL[prec] * 4.0, (tile, prec, err)
+
+
+def test_conv_f32_256x128_tile(ops):
+    """The 8-wave 256 x 128 instance of the fp32 LDS-DMA GEMM (tile 7): expand / project / 3x3 shapes, ragged M and
+    Cout, BN + ReLU6 + residual."""
+    for (n, h, w, cin, cout, taps, use_res) in [(3, 20, 23, 256, 1536, 1, False), (2, 20, 23, 1536, 256, 1, True),
+                                               (2, 12, 15, 64, 256, 9, False), (2, 20, 23, 72, 200, 1, True),
+                                               (1, 45, 80, 448, 256, 9, False)]:
+        x = rnd((n, cin, h, w), 71, 2.0)
+        k = 3 if taps == 9 else 1
+        wt = rnd((cout, cin, k, k), 72, 1.0 / (cin * taps) ** 0.5)
+        scale, bias = rnd((cout,), 73, 0.5) + 1.0, rnd((cout,), 74, 0.1)
+        ref = torch.clamp(F.conv2d(x, wt, padding=k // 2) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1), 0, 6)
+        res = rnd((n, cout, h, w), 75) if use_res else None
+        if use_res:
+            ref = ref + res
+        got = ops.conv_gemm(nhwc(x), wt, scale, bias, act=1, res=nhwc(res) if use_res else None, prec="f32", tile=7)
+        err = (nchw(got) - ref).abs().max().item()
+        assert err <= TOL["f32"] * 4.0, ((n, h, w, cin, cout, taps), err)
 
 
 @pytest.mark.parametrize("tile", [1, 5, 6])
