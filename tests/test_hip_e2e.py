@@ -349,3 +349,43 @@ def test_lstm_variant_vs_reference_golden_and_oracle(golden_dir, prec):
         ss = int(g["state_stride"])
         assert np.abs(st[0].cpu().contiguous().view(-1).numpy()[::ss] - g["state" + sfx]).max() <= STATE_TOL[prec]
         assert np.abs(st[1].cpu().contiguous().view(-1).numpy()[::ss] - g["cstate" + sfx]).max() <= STATE_TOL[prec]
+
+
+def test_inputs_are_read_in_place_and_never_modified(hip_model):
+    """The launch loop binds the caller's tensors (no staging copy): contiguous and non-contiguous inputs give the
+    same result, and nothing the caller passed is written to (SURVEY.md 8(b) Ownership)."""
+    x, cb = make_inputs(4, 96, 160)
+    hip_model.time_dims, hip_model.precision = 4, "f32"
+    xd, g, o = x.cuda(), cb[0].cuda(), cb[1].cuda()
+    st = torch.rand((1, 256, 12, 20), generator=torch.Generator().manual_seed(9)).cuda()
+    keep = [t.clone() for t in (xd, g, o, st)]
+    a, sa = hip_model(xd, [g, o], [st])
+    # non-contiguous views of the same values: channels-last frames, a strided slice of a wider prior tensor
+    x_cl = xd.to(memory_format=torch.channels_last)
+    g_wide = torch.zeros((4, 16, 12, 20), device="cuda")
+    g_wide[:, ::2] = g
+    b, sb = hip_model(x_cl, [g_wide[:, ::2], o], [st.permute(0, 1, 3, 2).contiguous().permute(0, 1, 3, 2)])
+    assert torch.equal(a, b) and torch.equal(sa[0], sb[0])
+    for t, k in zip((xd, g, o, st), keep):
+        assert torch.equal(t, k)
+
+
+def test_in_place_weight_edit_rebuilds_the_plan(hip_model):
+    """Engines are built from the parameter values; an in-place edit (param.data.copy_, an optimizer step) is
+    detected by the version scan and the plan is rebuilt instead of silently using stale packed weights."""
+    x, cb = make_inputs(4, 96, 160)
+    hip_model.time_dims, hip_model.precision = 4, "f32"
+    args = (x.cuda(), [cb[0].cuda(), cb[1].cuda()], None)
+    a, _ = hip_model(*args)
+    wt = hip_model.conv_out_st.conv[3].weight          # BatchNorm gamma of the decoder's projection
+    old = wt.detach().clone()
+    try:
+        with torch.no_grad():
+            wt.mul_(0.5)
+        b, _ = hip_model(*args)
+        assert (a - b).abs().max().item() > 1e-3         # the new weights were used
+    finally:
+        with torch.no_grad():
+            wt.copy_(old)
+    c, _ = hip_model(*args)
+    assert torch.equal(a, c)
