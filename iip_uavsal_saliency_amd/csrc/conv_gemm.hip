@@ -237,6 +237,9 @@ __device__ __attribute__((aligned(16))) float g_zero16[4];
 #ifndef UAVSAL_SK_ACQUIRE
 #define UAVSAL_SK_ACQUIRE 1
 #endif
+#ifndef UAVSAL_H16_STAGGER
+#define UAVSAL_H16_STAGGER 1
+#endif
 #ifndef UAVSAL_GEMM_PREFETCH
 #define UAVSAL_GEMM_PREFETCH 2
 #endif
@@ -1142,11 +1145,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_gemm_h16_dma_k
     const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
     const int lr = lane & 31, lh = lane >> 5;
 
-    auto compute = [&](int stage) {
+    auto compute_half = [&](int stage, int s) {      // sub-step s (16 of the K step's 32 channels)
         const char* As = smem + stage * STAGE;
         const char* Bs = As + APAN;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        {
             const int chunk = 2 * s + lh;        // hi chunk; the lo chunk is slot chunk + 4
             u32x4 af[WM][2], bfr[WN][2];
 #pragma unroll
@@ -1194,17 +1196,17 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_gemm_h16_dma_k
             if (D > 1 && kt + D <= nst) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PPW * (D > 1 ? D - 1 : 0)) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();        // every wave's have; and stage kt-1 (refilled next) is read out
-            if (kt + D < nst) {
-#ifdef UAVSAL_PROBE
-                if (p.act != 102)
-#endif
-                issue_stage(istage);
-                istage = (istage + 1 == S) ? 0 : istage + 1;
-            }
-#ifdef UAVSAL_PROBE
-            if (p.act != 101)
-#endif
-            compute(stage);
+            // The request burst of a stage blocks the issuing wave for ~2000 cycles (the memory pipe accepts 64 KB
+            // no faster), and two waves share each SIMD's matrix pipe.  So the second wave of every SIMD (waves
+            // NW/2 .. NW-1) issues its burst in the MIDDLE of the K step: while one wave of a SIMD is blocked the
+            // other multiplies (MI355X_MICROARCH.md, two waves per SIMD, item 9).
+            const bool do_issue = kt + D < nst;
+            const bool late = UAVSAL_H16_STAGGER && NW == 8 && wave_u >= NW / 2;
+            if (do_issue && !late) issue_stage(istage);
+            compute_half(stage, 0);
+            if (do_issue && late) issue_stage(istage);
+            compute_half(stage, 1);
+            if (do_issue) istage = (istage + 1 == S) ? 0 : istage + 1;
             stage = (stage + 1 == S) ? 0 : stage + 1;
         }
 
