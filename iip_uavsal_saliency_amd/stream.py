@@ -17,7 +17,8 @@ from . import ops
 
 @torch.no_grad()
 def predict_video(model, frames_u8: torch.Tensor, gauss_prior: torch.Tensor, ob_prior: torch.Tensor,
-                  batch_size: int = 4, out_size: Optional[tuple] = None, return_maps: bool = False):
+                  batch_size: int = 4, out_size: Optional[tuple] = None, return_maps: bool = False,
+                  persistent_state: bool = True):
     """`frames_u8` uint8 `[F,3,H,W]` RGB (already letterboxed to the model size, as
     preprocess_videos does, utils_data.py:255-287), `gauss_prior` `[8,h,w]`, `ob_prior` `[20,h,w]`
     float32 (one map set, repeated per frame like get_bias, Demo_Test.py:14-27).
@@ -39,14 +40,21 @@ def predict_video(model, frames_u8: torch.Tensor, gauss_prior: torch.Tensor, ob_
     steps = math.ceil(count_bs / batch_size)
     state = None
     maps = []
-    for i in range(steps):
-        x = frames_u8[i * group:(i + 1) * group]
-        n = x.shape[0]
-        cb = [gauss_prior.to(dev).unsqueeze(0).expand(n, -1, -1, -1).contiguous(),
-              ob_prior.to(dev).unsqueeze(0).expand(n, -1, -1, -1).contiguous()]
-        out, st = model(x, cb, state)
-        state = [st[0]]
-        maps.append(out)
+    was = model.persistent_state
+    model.persistent_state = bool(persistent_state)
+    try:
+        for i in range(steps):
+            x = frames_u8[i * group:(i + 1) * group]
+            n = x.shape[0]
+            cb = [gauss_prior.to(dev).unsqueeze(0).expand(n, -1, -1, -1).contiguous(),
+                  ob_prior.to(dev).unsqueeze(0).expand(n, -1, -1, -1).contiguous()]
+            out, st = model(x, cb, state)
+            # persistent mode: st[0] is a view of the engine's state buffer (valid until the next call, which
+            # recognises it by address); a shorter last group runs on another plan, which loads it as a tensor
+            state = [st[0].detach()]
+            maps.append(out)
+    finally:
+        model.persistent_state = was
     maps = torch.cat(maps, 0)
     sal = ops.postprocess_predictions(maps, out_size[0], out_size[1])
     return (sal, maps) if return_maps else sal

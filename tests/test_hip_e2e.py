@@ -318,6 +318,14 @@ def test_predict_video_equals_manual_loop(hip_model, oracle):
     hip_model.time_dims, hip_model.precision = T, "f32"
     sal, maps = predict_video(hip_model, torch.from_numpy(u8), gp, op, batch_size=2, return_maps=True)
     assert sal.shape == (8, H, W) and sal.dtype == torch.uint8
+    # state kept in the engine's buffer between groups (default) == re-fed state, bit for bit; and a last group
+    # of a different length (9 frames of time_dims 2 in groups of 3 chunks: 6 + 2) hands the state to another plan
+    sal2, maps2 = predict_video(hip_model, torch.from_numpy(u8), gp, op, batch_size=2, return_maps=True,
+                                persistent_state=False)
+    assert torch.equal(maps, maps2) and torch.equal(sal, sal2)
+    m3a = predict_video(hip_model, torch.from_numpy(u8), gp, op, batch_size=3, return_maps=True)[1]
+    m3b = predict_video(hip_model, torch.from_numpy(u8), gp, op, batch_size=3, return_maps=True, persistent_state=False)[1]
+    assert torch.equal(m3a, m3b)
     oracle.time_dims = T
     state, ref_maps = None, []
     for i in range(2):
