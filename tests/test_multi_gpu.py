@@ -1,8 +1,14 @@
 """Multi-GPU equivalence of the clip-sharded path: W ranks, one process per GPU over
-RCCL, each running the HIP model on its own clips + ONE all-gather of the maps == the same clips on a
-single GPU, bit for bit.  Needs >= 2 visible GPUs (skipped on the 1-GPU box); the ranks are fresh child
-processes started before this process makes any GPU call (device_count() does not initialise HIP here).
-The partitioning / gather logic itself is covered on CPU by the gloo test in test_host_cpu.py."""
+RCCL, each running the HIP model on its own clips + ONE all-gather of the maps.  Checked on rank 0:
+  * bit for bit against the same shards run one after another on ONE GPU (same per-launch shapes, so the
+    same tiles / stream-K partition and the same summation order) -- this is what sharding must preserve;
+  * within the fp32 parity tolerance against the whole batch in one `forward_clips` call: the GEMM tile walk
+    and stream-K partition depend on the number of images in a launch, so a different batch size changes the
+    summation order (measured on one GPU: 8 clips vs the same clips as 2 x 4 differ by up to 1.3e-4 on the
+    map of this synthetic network, which amplifies fp32 round-off ~10^3 times).
+Needs >= 2 visible GPUs (skipped on the 1-GPU box); the ranks are fresh child processes started before this
+process makes any GPU call (device_count() does not initialise HIP here).  The partitioning / gather logic
+itself is covered on CPU by the gloo test in test_host_cpu.py."""
 import os
 import socket
 import subprocess
@@ -44,12 +50,23 @@ out, st = forward_clips_sharded(model, x, cb, None, total_clips=C)
 out2, st2 = forward_clips_sharded(model, x, cb, st, total_clips=C)      # carried local states
 torch.cuda.synchronize()
 if rank == 0:
-    xa, cba = clips(0, C)                                # single-GPU run of the whole batch, same process
-    ref, rst = model.forward_clips(xa, cba, None)
-    ref2, rst2 = model.forward_clips(xa, cba, rst)
-    ok = (torch.equal(out, ref) and torch.equal(out2, ref2) and torch.equal(st, rst[:sh.count])
-          and torch.equal(st2, rst2[:sh.count]))
-    print("MULTIGPU_RESULT", "OK" if ok else "MISMATCH", float((out - ref).abs().max()), flush=True)
+    # (a) every rank's shard run alone on this GPU, one after another: bit-identical to the gathered result
+    refs, refs2, ok = [], [], True
+    for r in range(world):
+        xr, cbr = clips(r * sh.count, sh.count)
+        o1, s1 = model.forward_clips(xr, cbr, None)
+        o2, s2 = model.forward_clips(xr, cbr, s1)
+        refs.append(o1); refs2.append(o2)
+        if r == 0:
+            ok = ok and torch.equal(st, s1) and torch.equal(st2, s2)      # states stay on the owning rank
+    ok = ok and torch.equal(out, torch.cat(refs)) and torch.equal(out2, torch.cat(refs2))
+    # (b) the whole batch in one call: same values up to summation order
+    xa, cba = clips(0, C)
+    full, fst = model.forward_clips(xa, cba, None)
+    full2, _ = model.forward_clips(xa, cba, fst)
+    tol = max(float((out - full).abs().max()), float((out2 - full2).abs().max()))
+    ok = ok and tol <= 5e-4
+    print("MULTIGPU_RESULT", "OK" if ok else "MISMATCH", tol, flush=True)
 dist.barrier()
 dist.destroy_process_group()
 '''
