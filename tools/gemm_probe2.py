@@ -1,4 +1,6 @@
-"""Probe of the pre-split (LDS-DMA) f16x3 GEMM: tile choice, with / without the output store."""
+"""Probe of the pre-split (LDS-DMA) f16x3 GEMM: tile choice, with / without the output store.
+The no-store / parts variants need the library built with UAVSAL_EXTRA_HIPCC_FLAGS=-DUAVSAL_PROBE
+(python -m iip_uavsal_saliency_amd.build --force); on the product build they time the full kernel."""
 import ctypes as C
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
