@@ -112,6 +112,7 @@ SYMBOLS = [
     ("uavsal_conv_gemm", C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     ("uavsal_conv_tile", C.c_int, [C.POINTER(ConvDesc)]),
     ("uavsal_conv_uses_split", C.c_int, [C.POINTER(ConvDesc)]),
+    ("uavsal_conv_dwproj", C.c_int, [C.POINTER(ConvDesc)]),
     ("uavsal_streamk_workspace_bytes", C.c_longlong, []),
     ("uavsal_conv_streamk_grid", C.c_int, [C.POINTER(ConvDesc)]),
     ("uavsal_dw3x3", C.c_int, [C.POINTER(DwDesc), C.c_void_p]),
@@ -172,7 +173,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.uavsal_abi_version() != 11:
+    if lib.uavsal_abi_version() != 12:
         raise RuntimeError("libuavsal_hip.so ABI version mismatch")
     for i, t in enumerate(DESC_TYPES):
         if lib.uavsal_sizeof_desc(i) != C.sizeof(t):

@@ -1008,6 +1008,335 @@ void conv_gemm_f32_dma_kernel(const ConvK p) {
 }
 
 // =====================================================================================
+// Depthwise 3x3 + BN + ReLU6 -> 1x1 projection + BN (+ residual) in ONE launch, fp32, LDS halo tile
+// (dwBlock, reference model.py:92-95): D = relu6(bn(dw3x3(E))) never reaches HBM.
+//
+// A workgroup owns an 8 x 16 pixel patch of one image (= the GEMM's 128-row M tile) and BN output channels,
+// and walks K in steps of 16 hidden channels.  Per step it
+//   * requests by LDS-DMA, four steps ahead: the 10 x 18 halo of E for those channels (64 B per pixel, rows
+//     padded to 19 slots; out-of-image pixels read a zero page = the convolution's zero padding), the step's
+//     depthwise taps / BN scale / BN bias (11 rows x 64 B, straight from the [9][C] tap-major array) and the
+//     BN x 64 B projection-weight panel.  A wave's requests are slotted between its MFMA groups (first wave of a
+//     SIMD: first half of the step, second wave: second half), with running per-lane source pointers: no address
+//     arithmetic beyond one 64-bit add per request;
+//   * computes the depthwise two steps ahead of the multiply, on ONE wave per SIMD (waves 0-3 on even
+//     steps, 4-7 on odd ones): a lane owns a 1 x 2 pixel strip x 4 channels, reads its 3 x 4 halo pixels
+//     (12 ds_read_b128 at immediate offsets from one base, conflict-free with the 19-slot row pitch) plus
+//     the 11 weight rows and writes two A-tile rows, while the SIMD's other wave keeps the matrix pipe busy;
+//   * multiplies the step whose fragments were read from LDS BEFORE the barrier (fragments are loaded one step
+//     ahead, half of them after the first half of the MFMAs), so no wave waits on LDS behind a barrier.
+// One barrier per K step; E slots x3, weight panels x4, A tiles x2.  A-tile row r holds the pixel
+// (y, x) = (4 r5 + r[2:1], 8 r6 + 2 (r0 + 2 r4) + r3) (r_i = bit i of r), which makes the depthwise stores of a
+// lane group fall on distinct banks; the epilogue inverts it.
+// Shapes: stride 1, dilation 1, hidden channels % 16 == 0 (host: dwproj_eligible).
+template <int WAVES_M, int WAVES_N, int WM, int WN>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 1) void dwproj_f32_kernel(const ConvK p) {
+    constexpr int PH = 8, PW = 16, HPITCH = PW + 3, NHSLOT = (PH + 2) * HPITCH;
+    constexpr int BM = PH * PW, BN = WAVES_N * WN * 32;
+    constexpr int NW = WAVES_M * WAVES_N, NT = NW * 64;
+    constexpr int KT = 16, DIST = 4;
+    constexpr int E_REQ = (NHSLOT + 15) / 16;         // 12 wave requests of 16 halo slots, then one for the dw weights
+    constexpr int W_OFF = E_REQ * 1024;               // [9 taps | scale | bias][16 channels] behind the halo
+    constexpr int E_SLOT = W_OFF + 1024, NE = 3;
+    constexpr int B_REQ = BN / 16, B_SLOT = BN * 64, NB = 4;
+    constexpr int A_SLOT = BM * 64;
+    constexpr int E_IT = (E_REQ + 1 + NW - 1) / NW, B_IT = (B_REQ + NW - 1) / NW, NREQ = E_IT + B_IT;
+    constexpr int NGRP = 2 * WM * WN, RPG = (NREQ + NGRP - 1) / NGRP;
+    constexpr int DW_ITEMS = BM * 4 / 2 / 64;         // waves' worth of (1 x 2 strip, 4 channels) items: 4
+    static_assert(WAVES_M * WM * 32 == BM, "the M tile is the 8 x 16 patch");
+    static_assert(2 * B_SLOT >= 32 * BN * 4, "epilogue staging = two weight panels");
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+    static_assert(NREQ <= 15, "vmcnt immediate");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    char* const Es = smem;
+    char* const Bs = smem + NE * E_SLOT;               // panels 2, 3 double as the epilogue staging
+    char* const As = Bs + NB * B_SLOT;
+
+    const int tid = threadIdx.x;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int wm = wave_u / WAVES_N, wn = wave_u - wm * WAVES_N;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int pwn = (p.W + PW - 1) / PW, phn = (p.H + PH - 1) / PH;
+    const int nst = p.Cin / KT;
+
+    const uavsal_tile_walk walk = xcd_tile_walk(blockIdx.x, gridDim.x, p.nblk);
+    int tile = walk.tile;
+    if (tile >= walk.end) return;
+
+    int img = 0, y0 = 0, x0 = 0, n0 = 0;
+    // request r of this lane: running source pointer, its per-step advance in bytes (0: zero page), LDS target
+    // relative to the slot (or -1: the scratch KB)
+    const char* rq_ptr[NREQ];
+    int rq_step[NREQ];
+    int rq_lds[NREQ];
+    int my_reqs = 0;                                   // requests this wave issues per K step
+#pragma unroll
+    for (int r = 0; r < NREQ; ++r) {
+        const int q = wave_u + (r < E_IT ? r : r - E_IT) * NW;
+        rq_lds[r] = (r < E_IT ? q <= E_REQ : q < B_REQ) ? q * 1024 : -1;
+        my_reqs += rq_lds[r] >= 0 ? 1 : 0;
+    }
+    // leaves exactly the youngest step's requests of THIS wave in flight
+    auto wait_all_but_youngest_step = [&]() {
+        switch (my_reqs) {
+            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+            case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
+    };
+    auto setup_tile = [&](int t) {
+        const int tm = t / p.tiles_n;
+        n0 = (t - tm * p.tiles_n) * BN;
+        img = tm / (phn * pwn);
+        const int rem = tm - img * (phn * pwn);
+        const int pyi = rem / pwn;
+        y0 = pyi * PH;
+        x0 = (rem - pyi * pwn) * PW;
+        const int ck = (lane & 3) * 4;
+#pragma unroll
+        for (int r = 0; r < NREQ; ++r) {
+            const float* src = nullptr;
+            if (r < E_IT) {
+                const int q = wave_u + r * NW;
+                if (q < E_REQ) {
+                    const int hs = q * 16 + (lane >> 2);
+                    const int hy = hs / HPITCH, hx = hs - hy * HPITCH;
+                    const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+                    if (hs < NHSLOT && hx < PW + 2 && y >= 0 && y < p.H && x >= 0 && x < p.W)
+                        src = p.a + ((long long)img * p.a_is + (long long)y * p.W + x) * p.lda + ck;
+                } else if (q == E_REQ) {
+                    const int seg = lane >> 2;
+                    if (seg < 9) src = p.dw_w + (size_t)seg * p.Cin + ck;
+                    else if (seg == 9) src = p.dw_s + ck;
+                    else if (seg == 10) src = p.dw_b + ck;
+                }
+            } else {
+                const int q = wave_u + (r - E_IT) * NW;
+                const int row = q * 16 + (lane >> 2);
+                const int lc = (lane & 3) ^ ((row >> 2) & 3);
+                const int nn = n0 + row;
+                if (q < B_REQ && nn < p.Npad) src = reinterpret_cast<const float*>(p.w) + (size_t)nn * p.Kpad + lc * 4;
+            }
+            rq_ptr[r] = reinterpret_cast<const char*>(src ? src : g_zero16);
+            rq_step[r] = src ? KT * 4 : 0;
+        }
+    };
+#ifdef UAVSAL_PROBE      // tools/dwproj_probe.py parts: act = 128 + bits {1 no MFMAs, 2 no depthwise, 4 no DMA requests,
+                         // 8 no fragment loads, 16 no barriers}
+    const int pr_bits = p.act >= 128 ? p.act - 128 : 0;
+    const bool pr_mul = !(pr_bits & 1), pr_dw = !(pr_bits & 2), pr_dma = !(pr_bits & 4), pr_frag = !(pr_bits & 8),
+               pr_bar = !(pr_bits & 16);
+#else
+    constexpr bool pr_mul = true, pr_dw = true, pr_dma = true, pr_frag = true, pr_bar = true;
+#endif
+    // request r (compile-time) of the next K step to be requested: E slot at byte offset eo, weight panel at bo
+    auto issue_one = [&](int r, int eo, int bo) {
+        if (!pr_dma || rq_lds[r] < 0) return;         // (wave-uniform)
+        char* dst = (r < E_IT ? Es + eo : Bs + bo) + rq_lds[r];
+        __builtin_amdgcn_global_load_lds((gptr_t)rq_ptr[r], (lptr_t)dst, 16, 0, 0);
+        rq_ptr[r] += rq_step[r];
+    };
+    auto issue_all = [&](int eo, int bo) {
+#pragma unroll
+        for (int r = 0; r < NREQ; ++r) issue_one(r, eo, bo);
+    };
+    // depthwise of one K step: E slot at es -> A tile at
+    auto depthwise = [&](const char* es, char* at) {
+        const int w4 = wave_u & 3;
+        const int cq = lane & 3, sx2 = (lane >> 2) & 3, syl = lane >> 4, half = w4 & 1, xh = w4 >> 1;
+        const char* eb = es + ((4 * half + syl) * HPITCH + 8 * xh + 2 * sx2) * 64 + cq * 16;
+        const char* wb = es + W_OFF + cq * 16;
+        f32x4 o[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) o[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            f32x4 e[4], w[3];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) e[j] = *reinterpret_cast<const f32x4*>(eb + (dy * HPITCH + j) * 64);
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) w[dx] = *reinterpret_cast<const f32x4*>(wb + (dy * 3 + dx) * 64);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    o[j].x = fmaf(e[j + dx].x, w[dx].x, o[j].x); o[j].y = fmaf(e[j + dx].y, w[dx].y, o[j].y);
+                    o[j].z = fmaf(e[j + dx].z, w[dx].z, o[j].z); o[j].w = fmaf(e[j + dx].w, w[dx].w, o[j].w);
+                }
+        }
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(wb + 9 * 64);
+        const f32x4 bi = *reinterpret_cast<const f32x4*>(wb + 10 * 64);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f32x4 d;
+            d.x = __builtin_amdgcn_fmed3f(fmaf(o[j].x, sc.x, bi.x), 0.f, 6.f);
+            d.y = __builtin_amdgcn_fmed3f(fmaf(o[j].y, sc.y, bi.y), 0.f, 6.f);
+            d.z = __builtin_amdgcn_fmed3f(fmaf(o[j].z, sc.z, bi.z), 0.f, 6.f);
+            d.w = __builtin_amdgcn_fmed3f(fmaf(o[j].w, sc.w, bi.w), 0.f, 6.f);
+            const int rho = (sx2 & 1) + 2 * syl + 8 * j + 16 * (sx2 >> 1) + 32 * half + 64 * xh;
+            *reinterpret_cast<f32x4*>(at + (rho * 4 + (cq ^ ((rho >> 2) & 3))) * 16) = d;
+        }
+    };
+    // which waves run the depthwise of K step s: all four of a 4-wave workgroup, else waves 0-3 / 4-7 in turn
+    auto is_dw_wave = [&](int s) { return pr_dw && (NW == 4 || (((wave_u >> 2) ^ s) & 1) == 0); };
+    f32x16 acc[WM][WN];
+    f32x4 af[2][WM], bfr[2][WN];                       // fragments of the K step about to be multiplied
+    auto load_frag = [&](const char* at, const char* bt, int u) {
+        if (!pr_frag) return;
+        const int chunk = 2 * u + lh;
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+            const int row = (wm * WM + i) * 32 + lr;
+            af[u][i] = *reinterpret_cast<const f32x4*>(at + (row * 4 + (chunk ^ ((row >> 2) & 3))) * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int row = (wn * WN + j) * 32 + lr;
+            bfr[u][j] = *reinterpret_cast<const f32x4*>(bt + (row * 4 + (chunk ^ ((row >> 2) & 3))) * 16);
+        }
+    };
+    // half u of the K step's MFMAs; the next requests are slotted behind the groups
+    auto multiply_half = [&](int u, bool do_req, int eo, int bo) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                if (pr_mul) {
+                    const f32x4 av = af[u][i], bv = bfr[u][j];
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[i][j], 0, 0, 0);
+                }
+                if (do_req) {
+                    // request slots: the first wave of each SIMD uses the groups of the first half, the second wave
+                    // those of the second half, so that the two are never both blocked in the memory pipe
+                    constexpr int HG = (NW == 8 && NREQ <= NGRP / 2) ? NGRP / 2 : 0;
+                    const int grp = (u * WM + i) * WN + j;
+                    if (HG == 0) {
+#pragma unroll
+                        for (int r = grp * RPG; r < (grp + 1) * RPG && r < NREQ; ++r) issue_one(r, eo, bo);
+                    } else if ((grp >= HG) == (wave_u >= 4)) {
+                        if ((grp % HG) < NREQ) issue_one(grp % HG, eo, bo);
+                    }
+                }
+            }
+    };
+
+    setup_tile(tile);
+    issue_all(0, 0);
+    if (nst > 1) issue_all(E_SLOT, B_SLOT);
+    while (true) {
+        const int cimg = img, cy0 = y0, cx0 = x0, cn0 = n0;
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
+        // ---- two lead-in steps: depthwise(0), depthwise(1), fragments of step 0
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // steps 0, 1 landed
+        if (2 < nst) issue_all(2 * E_SLOT, 2 * B_SLOT);
+        if (is_dw_wave(0)) depthwise(Es, As);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                // A tile 0 written
+        if (3 < nst) issue_all(0, 3 * B_SLOT);
+        if (1 < nst && is_dw_wave(1)) depthwise(Es + E_SLOT, As + A_SLOT);
+        load_frag(As, Bs, 0);
+        load_frag(As, Bs, 1);
+        // byte offsets of: the E slot of step kt + 4 (= kt + 1 mod 3) and of step kt + 2; panel of kt + 4 (= kt mod 4)
+        int e_req = E_SLOT, e_dw = 2 * E_SLOT;
+        for (int kt = 0; kt < nst; ++kt) {
+            // own requests of step kt + 2 landed (one younger step may stay in flight), own LDS accesses done,
+            // then everyone's (one statement: nothing moves in between)
+            if (kt + 3 < nst) wait_all_but_youngest_step();
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (pr_bar) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            const bool do_req = kt + DIST < nst;
+            const int b_req = (kt & 3) * B_SLOT, b_frag = ((kt + 1) & 3) * B_SLOT;
+            char* a_dw = As + (kt & 1) * A_SLOT;                    // A tile of step kt + 2
+            const char* a_frag = As + ((kt + 1) & 1) * A_SLOT;
+            if (kt + 2 < nst && is_dw_wave(kt)) depthwise(Es + e_dw, a_dw);
+            multiply_half(0, do_req, e_req, b_req);
+            if (kt + 1 < nst) load_frag(a_frag, Bs + b_frag, 0);
+            multiply_half(1, do_req, e_req, b_req);
+            if (kt + 1 < nst) load_frag(a_frag, Bs + b_frag, 1);
+            e_req = e_req == 2 * E_SLOT ? 0 : e_req + E_SLOT;
+            e_dw = e_dw == 2 * E_SLOT ? 0 : e_dw + E_SLOT;
+        }
+        const bool has_next = tile + walk.stride < walk.end;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave is past its LDS reads
+        if (has_next) {
+            tile += walk.stride;
+            setup_tile(tile);
+            issue_all(0, 0);                       // E slots 0, 1 / weight panels 0, 1; the staging below uses panels 2, 3
+            if (nst > 1) issue_all(E_SLOT, B_SLOT);
+        }
+        // ---- epilogue: BN, activation, residual; 32-row blocks of the A-tile order through LDS
+        {
+            float* stg = reinterpret_cast<float*>(Bs + 2 * B_SLOT);
+            const bool vec = !(p.ldc & 3) && !(p.Cout & 3) && !((size_t)p.out & 15) &&
+                             (!p.res || (!(p.ldr & 3) && !((size_t)p.res & 15)));
+            float sc[WN], bi[WN];
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                const int c = cn0 + (wn * WN + j) * 32 + lr;
+                const bool okn = p.scale != nullptr && c < p.Cout;
+                sc[j] = okn ? p.scale[c] : 1.f;
+                bi[j] = okn ? p.bias[c] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int w = 0; w < WAVES_M; ++w) {
+                    const int pp = w * WM + i;
+                    if (wm == w) {
+#pragma unroll
+                        for (int g = 0; g < 16; ++g) {
+                            const int r = (g & 3) + 8 * (g >> 2) + 4 * lh;
+#pragma unroll
+                            for (int j = 0; j < WN; ++j)
+                                stg[r * BN + (wn * WN + j) * 32 + lr] = apply_act(fmaf(acc[i][j][g], sc[j], bi[j]), p.act);
+                        }
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int it = 0; it < (32 * BN / 4 + NT - 1) / NT; ++it) {
+                        const int idx = tid + it * NT;
+                        const int row = idx / (BN / 4), c4 = idx - row * (BN / 4);
+                        const int rho = pp * 32 + row;              // A-tile row -> pixel (header comment)
+                        const int y = cy0 + 4 * ((rho >> 5) & 1) + ((rho >> 1) & 3);
+                        const int x = cx0 + 8 * (rho >> 6) + 2 * ((rho & 1) + 2 * ((rho >> 4) & 1)) + ((rho >> 3) & 1);
+                        const int gn = cn0 + c4 * 4;
+                        if (row < 32 && y < p.H && x < p.W && gn < p.Cout) {
+                            f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * BN + c4 * 4);
+                            const long long pix = (long long)y * p.W + x;
+                            float* o = p.out + ((long long)cimg * p.o_is + pix) * p.ldc + gn;
+                            const float* rs = p.res ? p.res + ((long long)cimg * p.r_is + pix) * p.ldr + gn : nullptr;
+                            if (vec) {
+                                if (rs) v += *reinterpret_cast<const f32x4*>(rs);
+                                *reinterpret_cast<f32x4*>(o) = v;
+                            } else {
+#pragma unroll
+                                for (int c = 0; c < 4; ++c)
+                                    if (gn + c < p.Cout) o[c] = v[c] + (rs ? rs[c] : 0.f);
+                            }
+                        }
+                    }
+                    __syncthreads();
+                }
+        }
+        if (!has_next) break;
+    }
+}
+
+// =====================================================================================
 // Split-fp16 path with PRE-SPLIT operands: LDS-DMA staged, S-stage ring, no conversion work.
 //
 // The register-staged kernel above re-splits the fp32 activations (hi = fp16(16 x), lo = fp16(16 x - hi)) in
@@ -1392,6 +1721,37 @@ int launch_h16_dma(const ConvK& k0, int taps, hipStream_t stream) {
     return uavsal_launch_status();
 }
 
+// LDS-halo depthwise -> projection (fp32): which descriptors take it, and the launch
+bool dwproj_eligible(const uavsal_conv_desc* d) {
+    static const bool on = [] { const char* e = getenv("UAVSAL_DWPROJ_LDS"); return !(e && e[0] == '0'); }();
+    return on && d->dw_w9c && d->prec == UAVSAL_PREC_F32 && d->taps == 1 && d->dw_stride == 1 && d->Cin % 16 == 0 &&
+           d->epi == UAVSAL_EPI_AFFINE;
+}
+
+template <int WAVES_M, int WAVES_N, int WM, int WN>
+int launch_dwproj_variant(const ConvK& k0, hipStream_t stream) {
+    constexpr int BN = WAVES_N * WN * 32, NT = WAVES_M * WAVES_N * 64;
+    constexpr int SMEM = 3 * (13 * 1024) + 4 * BN * 64 + 2 * 128 * 64;   // E slots, weight panels, A tiles
+    ConvK k = k0;
+    k.tiles_n = (k.Cout + BN - 1) / BN;
+    k.nblk = (k.M / k.HW) * ((k.H + 7) / 8) * ((k.W + 15) / 16) * k.tiles_n;
+    static const int cap = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwproj_f32_kernel<WAVES_M, WAVES_N, WM, WN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        return resident_grid(dwproj_f32_kernel<WAVES_M, WAVES_N, WM, WN>, SMEM, NT);
+    }();
+    const int grid = k.nblk < cap ? k.nblk : cap;
+    hipLaunchKernelGGL((dwproj_f32_kernel<WAVES_M, WAVES_N, WM, WN>), dim3(grid), dim3(NT), SMEM, stream, k);
+    return uavsal_launch_status();
+}
+
+int launch_dwproj(const ConvK& k, hipStream_t stream) {
+    if (k.Cout > 128) return launch_dwproj_variant<2, 4, 2, 2>(k, stream);   // 128 x 256, 8 waves
+    if (k.Cout > 64) return launch_dwproj_variant<2, 4, 2, 1>(k, stream);    // 128 x 128, 8 waves
+    if (k.Cout > 32) return launch_dwproj_variant<4, 2, 1, 1>(k, stream);    // 128 x 64,  8 waves
+    return launch_dwproj_variant<4, 1, 1, 1>(k, stream);                     // 128 x 32,  4 waves
+}
+
 // pre-split path: 256 x 256 / 128 x 256 on 8 waves, 128 x 128 on 4 (two workgroups per CU)
 int launch_h16(const ConvK& k, int taps, int tile, hipStream_t stream) {
     if (tile == 6) return launch_h16_dma<2, 4, 4, 2, 2>(k, taps, stream);    // 2 x 64 KB ring
@@ -1511,6 +1871,11 @@ extern "C" int uavsal_conv_uses_split(const uavsal_conv_desc* d) {
     return split_eligible(d, effective_tile(d)) ? 1 : 0;
 }
 
+extern "C" int uavsal_conv_dwproj(const uavsal_conv_desc* d) {
+    if (!d || d->n_img <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0 || !dwproj_eligible(d)) return 0;
+    return d->Cout > 128 ? 256 : (d->Cout > 64 ? 128 : (d->Cout > 32 ? 64 : 32));
+}
+
 extern "C" int uavsal_conv_gemm(const uavsal_conv_desc* d, uavsal_stream_t stream) {
     if (!d || !d->w || !d->out) return UAVSAL_EINVAL;
     if (!d->a && !(d->a_split && d->epi == UAVSAL_EPI_AFFINE)) return UAVSAL_EINVAL;
@@ -1584,6 +1949,7 @@ extern "C" int uavsal_conv_gemm(const uavsal_conv_desc* d, uavsal_stream_t strea
     k.a_sp = (const _Float16*)d->a_split; k.ldas = d->ldas;
     k.out_sp = (_Float16*)d->out_split; k.ldos = d->ldos;
     if (split_eligible(d, tile)) return launch_h16(k, d->taps, tile, s);
+    if (dwproj_eligible(d)) return launch_dwproj(k, s);
     if (!d->a) return UAVSAL_EINVAL;             // pre-split operands given but the shape is not eligible
     {
         const int G = streamk_plan(d, tile, k.ktiles);

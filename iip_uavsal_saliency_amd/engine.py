@@ -59,6 +59,11 @@ class V:
                  self.sp, self.key)
 
 
+# expanded values (pixels x hidden channels) from which the fused depthwise -> projection launch beats depthwise +
+# projection launches (tools/dwproj_probe.py: 8 x 45 x 80 x 1152 wins, 2 x 23 x 41 x 96 loses)
+FUSE_DW_MIN_WORK = 8 * 45 * 80 * 512
+
+
 class Engine:
     def __init__(self, model, device, n_seq, seq_len, H, W, ctx_T, ctx_mode="tile",
                  precision="f32", taps=False, in_dtype=torch.float32, use_graph=False, fuse_dw=None,
@@ -87,10 +92,12 @@ class Engine:
         self._err = None
         self._sk_debug = tuple(getattr(model, "_sk_debug", (0, 0)))
         # fused depthwise->projection GEMM (uavsal_conv_desc.dw_*): D never reaches HBM.
-        # Measured (profiles/README.md): as written -- nine dependent global loads per staged value, no
-        # LDS-staged halo tile -- the fused loader is latency-bound and ~1.5x SLOWER end to end, so it is
-        # off unless asked for; kept as a correct, tested building block for a later halo-staged version.
-        self.fuse_dw = False if fuse_dw is None else bool(fuse_dw)
+        #   None (default): the fp32 LDS-halo kernel (dwproj_f32_kernel) on the blocks where it wins -- stride 1,
+        #     dilation 1, hidden % 16 == 0 and at least FUSE_DW_MIN_WORK expanded values (the 45x80 / 90x160 dwBlocks
+        #     of the head and the decoder: profiles/r2_dwproj.md); other precisions keep the three-launch form;
+        #   True: every dilation-1 block with an expand conv (strides 2 and the 16-bit precisions then run the
+        #     round-1 register-staged loader, which is correct but ~1.5x slower: tests only);  False: never.
+        self.fuse_dw = fuse_dw if fuse_dw is None else bool(fuse_dw)
         if self.N % ctx_T:
             raise RuntimeError("frame count %d is not a multiple of time_dims %d" % (self.N, ctx_T))
         self.h = _down(_down(_down(H)))
@@ -280,6 +287,9 @@ class Engine:
         hw = a.h * a.w
         flops = 2.0 * n_img * hw * cin * cout * taps
         byts = 4.0 * n_img * hw * (cin + cout) + 4.0 * cin * cout * taps
+        if dw is not None:      # the launch also does the depthwise: reads E (hin x win), D never exists
+            flops += 18.0 * n_img * hw * cin
+            byts = 4.0 * n_img * (hin * win * cin + hw * cout) + 4.0 * cin * (cout + 11)
         self._meta(kind="conv%d" % (3 if taps == 9 else 1), name=name, flops=flops, bytes=byts,
                    M=n_img * hw, K=cin * taps, Nc=cout)
         # split shadows (f16x3): can this launch write one for its output / read its input pre-split?
@@ -352,6 +362,7 @@ class Engine:
         self.ops_meta[-1]["split"] = split
         self.ops_meta[-1]["tile"] = int(self.lib.uavsal_conv_tile(C.byref(d)))
         self.ops_meta[-1]["streamk"] = int(self.lib.uavsal_conv_streamk_grid(C.byref(d)))
+        self.ops_meta[-1]["dwproj"] = int(self.lib.uavsal_conv_dwproj(C.byref(d)))
         self._add(self.lib.uavsal_plan_add_conv, d, "plan_add_conv(%s)" % name)
 
     def dw(self, name, a: V, conv, bn, out: V, stride, dilation):
@@ -469,7 +480,9 @@ class Engine:
             e = x
             dwc, dwbn, pl, plbn = seq[0][0], seq[0][1], seq[1], seq[2]
         ho, wo = (x.h - 1) // stride + 1, (x.w - 1) // stride + 1
-        if self.fuse_dw and dil == 1 and blk.expand_ratio != 1:
+        if dil == 1 and blk.expand_ratio != 1 and (self.fuse_dw or (
+                self.fuse_dw is None and self.prec_name == "f32" and stride == 1 and blk.hidden % 16 == 0
+                and x.n * x.h * x.w * blk.hidden >= FUSE_DW_MIN_WORK)):
             # depthwise computed inside the projection GEMM's loader: D never reaches HBM
             self.conv(name + ".dwpl", e, pl, plbn, out, final_act, res=x if blk.use_res_connect else None,
                       dw=(dwc, dwbn, stride))
@@ -816,7 +829,8 @@ class Engine:
         self._patch("gauss.in", 0, cb0.data_ptr())
         self._patch("ob.in", 0, cb1.data_ptr())
         out = torch.empty((self.N, self.h * self.w), dtype=torch.float32, device=dev)
-        self._patch("conv_out_st.pl", 1, out.data_ptr())
+        # (the decoder's last launch: ".dwpl" when its depthwise runs inside the projection)
+        self._patch("conv_out_st.pl" if "conv_out_st.pl" in self._op_idx else "conv_out_st.dwpl", 1, out.data_ptr())
         self._patch("guard", 0, out.data_ptr())
         hold = [x, cb0, cb1, out]
         st = None

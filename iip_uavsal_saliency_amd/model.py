@@ -163,7 +163,7 @@ class UAVSal(nn.Module):
         self.time_dims = time_dims
         self.precision = precision
         self.use_graph = False          # replay the launch plan as one hipGraph
-        self.fuse_dw = None             # None: engine default (off; see engine.py)
+        self.fuse_dw = None             # None: engine default (fp32: LDS-halo fused dw->projection on the big blocks; engine.py)
         self.use_lanes = True           # independent branches on parallel streams / graph branches
         self.stream_k = True            # fp32 GEMMs: split K across workgroups when whole tiles leave CUs idle
         self.presplit = True            # f16x3: producers also write hi/lo fp16 shadows, GEMMs stage them by LDS-DMA

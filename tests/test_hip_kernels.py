@@ -267,6 +267,56 @@ def test_fused_depthwise_projection(ops, prec, case):
     assert err <= TOL[prec] * 8.0, (case, prec, err)
 
 
+# LDS-halo depthwise -> projection kernel (dwproj_f32_kernel): every instance (output tile 256 / 128 / 64 / 32), maps
+# that are not multiples of the 8 x 16 patch, one row / one column maps, several images (tile walk), residual,
+# sigmoid + Cout = 1 (scalar store path: the decoder's last launch), output / residual as channel slices
+DWPROJ_CASES = [
+    # n, h, w, hidden, cout, act, residual, sliced output
+    (1, 45, 80, 1536, 256, 0, True, False), (2, 45, 80, 320, 1, 2, False, False), (3, 13, 21, 96, 192, 1, False, False),
+    (2, 9, 17, 48, 128, 0, True, True), (1, 8, 16, 64, 64, 0, False, False), (2, 1, 37, 32, 40, 1, False, True),
+    (1, 23, 1, 16, 24, 0, False, False), (17, 7, 5, 80, 32, 2, False, False), (1, 90, 160, 64, 256, 0, False, False),
+    (40, 17, 33, 16, 300, 0, True, False),
+]
+
+
+@pytest.mark.parametrize("case", DWPROJ_CASES)
+def test_depthwise_projection_lds_halo(ops, case):
+    """dwBlock tail (model.py:92-95) in one launch with the halo tile in LDS == the two convs in fp32 torch."""
+    from iip_uavsal_saliency_amd import _lib as L
+    import ctypes as C
+    n, h, w, c, cout, act, use_res, sliced = case
+    e = rnd((n, c, h, w), 251, 3.0).clamp(0, 6)
+    wd = rnd((c, 1, 3, 3), 252, 0.4)
+    sd, bd = rnd((c,), 253) * 0.5 + 1.0, rnd((c,), 254)
+    wp = rnd((cout, c, 1, 1), 255, 1.0 / np.sqrt(c))
+    sp, bp = rnd((cout,), 256) * 0.5 + 1.0, rnd((cout,), 257)
+    dmid = torch.clamp(F.conv2d(e, wd, padding=1, groups=c) * sd.view(1, -1, 1, 1) + bd.view(1, -1, 1, 1), 0, 6)
+    ref = F.conv2d(dmid, wp) * sp.view(1, -1, 1, 1) + bp.view(1, -1, 1, 1)
+    ref = torch.clamp(ref, 0, 6) if act == 1 else (torch.sigmoid(ref) if act == 2 else ref)
+    res = rnd(tuple(ref.shape), 258) if use_res else None
+    if use_res:
+        ref = ref + res
+    d = L.ConvDesc()
+    d.n_img, d.H, d.W, d.Cin, d.Cout, d.taps, d.prec, d.epi = n, h, w, c, cout, 1, L.PREC["f32"], L.EPI_AFFINE
+    d.dw_w9c, d.dw_stride, d.out = 1 << 20, 1, 1 << 20
+    inst = int(L.load().uavsal_conv_dwproj(C.byref(d)))
+    assert inst == (256 if cout > 128 else 128 if cout > 64 else 64 if cout > 32 else 32)
+    pad = 8 if sliced else 0            # the output (and residual) are channel slices of wider NHWC buffers
+    dev = nhwc(e).device
+    outbuf = torch.full((n, h, w, cout + 2 * pad), 7.0, device=dev)
+    out = outbuf[..., pad:pad + cout]
+    rbuf = None
+    if use_res:
+        rbuf = torch.zeros((n, h, w, cout + 2 * pad), device=dev)
+        rbuf[..., pad:pad + cout] = nhwc(res)
+    got = ops.conv_gemm(nhwc(e), wp, sp, bp, act=act, res=rbuf[..., pad:pad + cout] if use_res else None, out=out,
+                        prec="f32", dw=(wd, sd, bd, 1))
+    err = (nchw(got.contiguous()) - ref).abs().max().item()
+    assert err <= 2e-5 * max(1.0, ref.abs().max().item()), (case, err)
+    if sliced:                          # nothing outside the slice was written
+        assert (outbuf[..., :pad] == 7.0).all() and (outbuf[..., pad + cout:] == 7.0).all()
+
+
 DW_CASES = [
     # n, h, w, c, stride, dilation
     (2, 9, 13, 48, 1, 1), (1, 12, 20, 120, 1, 1), (2, 45, 80, 1536, 1, 1), (1, 23, 41, 96, 2, 1),
