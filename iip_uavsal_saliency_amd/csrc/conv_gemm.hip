@@ -30,6 +30,7 @@
 //     (M tile, N tile) pairs: the N tiles that re-read one activation tile run on the
 //     same L2.
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -230,6 +231,9 @@ __device__ __forceinline__ f32x4 prescale(f32x4 x) {
 // 16 bytes of zeros: what out-of-range lanes (M / K tails, 3x3 zero padding) fetch instead of
 // being masked off
 __device__ __attribute__((aligned(16))) float g_zero16[4];
+// zeros for a whole K walk (dwproj_f32_kernel: out-of-image halo pixels advance through it like real rows do)
+#define UAVSAL_DWPROJ_MAX_C 4096
+__device__ __attribute__((aligned(16))) float g_zero_row[UAVSAL_DWPROJ_MAX_C + 16];
 
 #ifndef UAVSAL_SK_PREFETCH
 #define UAVSAL_SK_PREFETCH 1
@@ -1016,16 +1020,21 @@ void conv_gemm_f32_dma_kernel(const ConvK p) {
 //   * requests by LDS-DMA, four steps ahead: the 10 x 18 halo of E for those channels (64 B per pixel, rows
 //     padded to 19 slots; out-of-image pixels read a zero page = the convolution's zero padding), the step's
 //     depthwise taps / BN scale / BN bias (11 rows x 64 B, straight from the [9][C] tap-major array) and the
-//     BN x 64 B projection-weight panel.  A wave's requests are slotted between its MFMA groups (first wave of a
-//     SIMD: first half of the step, second wave: second half), with running per-lane source pointers: no address
-//     arithmetic beyond one 64-bit add per request;
-//   * computes the depthwise two steps ahead of the multiply, on ONE wave per SIMD (waves 0-3 on even
-//     steps, 4-7 on odd ones): a lane owns a 1 x 2 pixel strip x 4 channels, reads its 3 x 4 halo pixels
+//     BN x 64 B projection-weight panel.  The requests are issued by the SECOND wave of every SIMD (waves 4-7),
+//     the same number by each (spare ones fetch the zero page into a scratch KB: the counted vmcnt is then one
+//     immediate), one behind each of its MFMA groups, with running per-lane source pointers: no branches, no
+//     address arithmetic beyond one 64-bit add per request;
+//   * computes the depthwise two steps ahead of the multiply, on the FIRST wave of every SIMD (waves 0-3, the
+//     older ones, at raised priority): a lane owns a 1 x 2 pixel strip x 4 channels, reads its 3 x 4 halo pixels
 //     (12 ds_read_b128 at immediate offsets from one base, conflict-free with the 19-slot row pitch) plus
 //     the 11 weight rows and writes two A-tile rows, while the SIMD's other wave keeps the matrix pipe busy;
 //   * multiplies the step whose fragments were read from LDS BEFORE the barrier (fragments are loaded one step
-//     ahead, half of them after the first half of the MFMAs), so no wave waits on LDS behind a barrier.
-// One barrier per K step; E slots x3, weight panels x4, A tiles x2.  A-tile row r holds the pixel
+//     ahead, half of them after the first half of the MFMAs, the other half after the last MFMA: those reads
+//     stay in flight ACROSS the barrier -- it only waits for the older LDS accesses -- which is why there is one
+//     more weight panel and A tile than the requests need).  Between a wave's last MFMA of a step and its first
+//     of the next there is nothing but that wait and the barrier: with one workgroup per CU every cycle spent
+//     there idles the matrix pipe (4096 MFMA cycles per step and SIMD).
+// One barrier per K step; E slots x3, weight panels x5, A tiles x3.  A-tile row r holds the pixel
 // (y, x) = (4 r5 + r[2:1], 8 r6 + 2 (r0 + 2 r4) + r3) (r_i = bit i of r), which makes the depthwise stores of a
 // lane group fall on distinct banks; the epilogue inverts it.
 // Shapes: stride 1, dilation 1, hidden channels % 16 == 0 (host: dwproj_eligible).
@@ -1038,9 +1047,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 1) void dwproj_f32_kernel(c
     constexpr int E_REQ = (NHSLOT + 15) / 16;         // 12 wave requests of 16 halo slots, then one for the dw weights
     constexpr int W_OFF = E_REQ * 1024;               // [9 taps | scale | bias][16 channels] behind the halo
     constexpr int E_SLOT = W_OFF + 1024, NE = 3;
-    constexpr int B_REQ = BN / 16, B_SLOT = BN * 64, NB = 4;
-    constexpr int A_SLOT = BM * 64;
-    constexpr int E_IT = (E_REQ + 1 + NW - 1) / NW, B_IT = (B_REQ + NW - 1) / NW, NREQ = E_IT + B_IT;
+    constexpr int B_REQ = BN / 16, B_SLOT = BN * 64, NB = 5;
+    constexpr int A_SLOT = BM * 64, NA = 3;
+    constexpr int NLW = 4;                            // waves that issue the requests: the second wave of each SIMD (8-wave
+                                                      // instances; the first one runs the depthwise), else all four
+    constexpr int E_IT = (E_REQ + 1 + NLW - 1) / NLW, B_IT = (B_REQ + NLW - 1) / NLW, NREQ = E_IT + B_IT;
     constexpr int NGRP = 2 * WM * WN, RPG = (NREQ + NGRP - 1) / NGRP;
     constexpr int DW_ITEMS = BM * 4 / 2 / 64;         // waves' worth of (1 x 2 strip, 4 channels) items: 4
     static_assert(WAVES_M * WM * 32 == BM, "the M tile is the 8 x 16 patch");
@@ -1053,6 +1064,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 1) void dwproj_f32_kernel(c
     char* const Es = smem;
     char* const Bs = smem + NE * E_SLOT;               // panels 2, 3 double as the epilogue staging
     char* const As = Bs + NB * B_SLOT;
+    char* const Scratch = As + NA * A_SLOT;            // 1 KB: where the spare requests land
 
     const int tid = threadIdx.x;
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1067,30 +1079,17 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 1) void dwproj_f32_kernel(c
     if (tile >= walk.end) return;
 
     int img = 0, y0 = 0, x0 = 0, n0 = 0;
-    // request r of this lane: running source pointer, its per-step advance in bytes (0: zero page), LDS target
-    // relative to the slot (or -1: the scratch KB)
+    // request r of this lane: running source pointer (64 bytes further every K step; lanes with nothing to fetch
+    // walk a row of zeros), LDS target relative to the slot (or -1: the scratch KB)
     const char* rq_ptr[NREQ];
-    int rq_step[NREQ];
     int rq_lds[NREQ];
-    int my_reqs = 0;                                   // requests this wave issues per K step
+    const bool loader = wave_u >= NW - NLW, dw_wave = wave_u < 4;       // wave roles (a 4-wave workgroup: both)
+    const int lw = wave_u - (NW - NLW);
 #pragma unroll
     for (int r = 0; r < NREQ; ++r) {
-        const int q = wave_u + (r < E_IT ? r : r - E_IT) * NW;
+        const int q = lw + (r < E_IT ? r : r - E_IT) * NLW;
         rq_lds[r] = (r < E_IT ? q <= E_REQ : q < B_REQ) ? q * 1024 : -1;
-        my_reqs += rq_lds[r] >= 0 ? 1 : 0;
     }
-    // leaves exactly the youngest step's requests of THIS wave in flight
-    auto wait_all_but_youngest_step = [&]() {
-        switch (my_reqs) {
-            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-            case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-            case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        }
-    };
     auto setup_tile = [&](int t) {
         const int tm = t / p.tiles_n;
         n0 = (t - tm * p.tiles_n) * BN;
@@ -1100,11 +1099,12 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 1) void dwproj_f32_kernel(c
         y0 = pyi * PH;
         x0 = (rem - pyi * pwn) * PW;
         const int ck = (lane & 3) * 4;
+        if (!loader) return;
 #pragma unroll
         for (int r = 0; r < NREQ; ++r) {
             const float* src = nullptr;
             if (r < E_IT) {
-                const int q = wave_u + r * NW;
+                const int q = lw + r * NLW;
                 if (q < E_REQ) {
                     const int hs = q * 16 + (lane >> 2);
                     const int hy = hs / HPITCH, hx = hs - hy * HPITCH;
@@ -1118,14 +1118,13 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 1) void dwproj_f32_kernel(c
                     else if (seg == 10) src = p.dw_b + ck;
                 }
             } else {
-                const int q = wave_u + (r - E_IT) * NW;
+                const int q = lw + (r - E_IT) * NLW;
                 const int row = q * 16 + (lane >> 2);
                 const int lc = (lane & 3) ^ ((row >> 2) & 3);
                 const int nn = n0 + row;
                 if (q < B_REQ && nn < p.Npad) src = reinterpret_cast<const float*>(p.w) + (size_t)nn * p.Kpad + lc * 4;
             }
-            rq_ptr[r] = reinterpret_cast<const char*>(src ? src : g_zero16);
-            rq_step[r] = src ? KT * 4 : 0;
+            rq_ptr[r] = reinterpret_cast<const char*>(src ? src : g_zero_row + ck);
         }
     };
 #ifdef UAVSAL_PROBE      // tools/dwproj_probe.py parts: act = 128 + bits {1 no MFMAs, 2 no depthwise, 4 no DMA requests,
@@ -1138,17 +1137,19 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 1) void dwproj_f32_kernel(c
 #endif
     // request r (compile-time) of the next K step to be requested: E slot at byte offset eo, weight panel at bo
     auto issue_one = [&](int r, int eo, int bo) {
-        if (!pr_dma || rq_lds[r] < 0) return;         // (wave-uniform)
-        char* dst = (r < E_IT ? Es + eo : Bs + bo) + rq_lds[r];
+        if (!pr_dma) return;
+        char* dst = rq_lds[r] < 0 ? Scratch : (r < E_IT ? Es + eo : Bs + bo) + rq_lds[r];
         __builtin_amdgcn_global_load_lds((gptr_t)rq_ptr[r], (lptr_t)dst, 16, 0, 0);
-        rq_ptr[r] += rq_step[r];
+        rq_ptr[r] += KT * 4;
     };
     auto issue_all = [&](int eo, int bo) {
+        if (!loader) return;
 #pragma unroll
         for (int r = 0; r < NREQ; ++r) issue_one(r, eo, bo);
     };
     // depthwise of one K step: E slot at es -> A tile at
     auto depthwise = [&](const char* es, char* at) {
+        __builtin_amdgcn_s_setprio(1);         // the wave's vector work ahead of its SIMD-mate's (the mate only issues MFMAs)
         const int w4 = wave_u & 3;
         const int cq = lane & 3, sx2 = (lane >> 2) & 3, syl = lane >> 4, half = w4 & 1, xh = w4 >> 1;
         const char* eb = es + ((4 * half + syl) * HPITCH + 8 * xh + 2 * sx2) * 64 + cq * 16;
@@ -1183,9 +1184,12 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 1) void dwproj_f32_kernel(c
             const int rho = (sx2 & 1) + 2 * syl + 8 * j + 16 * (sx2 >> 1) + 32 * half + 64 * xh;
             *reinterpret_cast<f32x4*>(at + (rho * 4 + (cq ^ ((rho >> 2) & 3))) * 16) = d;
         }
+        __builtin_amdgcn_s_setprio(0);
     };
     // which waves run the depthwise of K step s: all four of a 4-wave workgroup, else waves 0-3 / 4-7 in turn
-    auto is_dw_wave = [&](int s) { return pr_dw && (NW == 4 || (((wave_u >> 2) ^ s) & 1) == 0); };
+    // the whole tile walk, instantiated per wave role (depthwise / requests / both): the two roles share no
+    // registers beyond the accumulators and fragments
+    auto run = [&](auto role_dw, auto role_ld) {
     f32x16 acc[WM][WN];
     f32x4 af[2][WM], bfr[2][WN];                       // fragments of the K step about to be multiplied
     auto load_frag = [&](const char* at, const char* bt, int u) {
@@ -1202,8 +1206,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 1) void dwproj_f32_kernel(c
             bfr[u][j] = *reinterpret_cast<const f32x4*>(bt + (row * 4 + (chunk ^ ((row >> 2) & 3))) * 16);
         }
     };
-    // half u of the K step's MFMAs; the next requests are slotted behind the groups
-    auto multiply_half = [&](int u, bool do_req, int eo, int bo) {
+    // half u of the K step's MFMAs; a loader wave's requests for the step four ahead are slotted behind the groups
+    auto multiply_half = [&](auto with_req, int u, int eo, int bo) {
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -1215,19 +1219,41 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 1) void dwproj_f32_kernel(c
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[i][j], 0, 0, 0);
                 }
-                if (do_req) {
-                    // request slots: the first wave of each SIMD uses the groups of the first half, the second wave
-                    // those of the second half, so that the two are never both blocked in the memory pipe
-                    constexpr int HG = (NW == 8 && NREQ <= NGRP / 2) ? NGRP / 2 : 0;
+                if (decltype(with_req)::value) {
                     const int grp = (u * WM + i) * WN + j;
-                    if (HG == 0) {
 #pragma unroll
-                        for (int r = grp * RPG; r < (grp + 1) * RPG && r < NREQ; ++r) issue_one(r, eo, bo);
-                    } else if ((grp >= HG) == (wave_u >= 4)) {
-                        if ((grp % HG) < NREQ) issue_one(grp % HG, eo, bo);
-                    }
+                    for (int r = grp * RPG; r < (grp + 1) * RPG && r < NREQ; ++r) issue_one(r, eo, bo);
                 }
             }
+    };
+    // one K step of the main loop.  eo_* / ao_* / bo_*: byte offsets of the slots of this step's roles
+    //   requests: step kt + 4 -> E slot eo_req, panel bo_req      depthwise: step kt + 2, E slot eo_dw -> A tile ao_dw
+    //   fragments: step kt + 1 <- A tile ao_frag, panel bo_frag
+    // FULL: steps kt + 1 .. kt + 4 all exist (no conditions in the body)
+    auto k_step = [&](auto full, auto role_dw, auto role_ld, int kt, int eo_req, int bo_req, int eo_dw, int ao_dw,
+                      int ao_frag, int bo_frag) {
+        constexpr bool FULL = decltype(full)::value, DW = decltype(role_dw)::value, LD = decltype(role_ld)::value;
+        // own requests of step kt + 2 landed (the youngest step may stay in flight); own LDS accesses done except the
+        // WM + WN fragment reads issued after the last MFMA; then everyone's
+        if (LD) {
+            if (FULL || kt + 3 < nst) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NREQ) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if (pr_bar) {
+            if (FULL || kt + 1 < nst) asm volatile("s_waitcnt lgkmcnt(%0)\n\ts_barrier" :: "n"(WM + WN) : "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        if (DW && pr_dw && (FULL || kt + 2 < nst)) depthwise(Es + eo_dw, As + ao_dw);
+        if (LD && (FULL || kt + DIST < nst)) {
+            multiply_half(std::true_type{}, 0, eo_req, bo_req);
+            if (FULL || kt + 1 < nst) load_frag(As + ao_frag, Bs + bo_frag, 0);
+            multiply_half(std::true_type{}, 1, eo_req, bo_req);
+        } else {
+            multiply_half(std::false_type{}, 0, 0, 0);
+            if (FULL || kt + 1 < nst) load_frag(As + ao_frag, Bs + bo_frag, 0);
+            multiply_half(std::false_type{}, 1, 0, 0);
+        }
+        if (FULL || kt + 1 < nst) load_frag(As + ao_frag, Bs + bo_frag, 1);
     };
 
     setup_tile(tile);
@@ -1244,32 +1270,29 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 1) void dwproj_f32_kernel(c
         // ---- two lead-in steps: depthwise(0), depthwise(1), fragments of step 0
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // steps 0, 1 landed
         if (2 < nst) issue_all(2 * E_SLOT, 2 * B_SLOT);
-        if (is_dw_wave(0)) depthwise(Es, As);
+        if (dw_wave && pr_dw) depthwise(Es, As);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                // A tile 0 written
         if (3 < nst) issue_all(0, 3 * B_SLOT);
-        if (1 < nst && is_dw_wave(1)) depthwise(Es + E_SLOT, As + A_SLOT);
+        if (1 < nst && dw_wave && pr_dw) depthwise(Es + E_SLOT, As + A_SLOT);
         load_frag(As, Bs, 0);
         load_frag(As, Bs, 1);
-        // byte offsets of: the E slot of step kt + 4 (= kt + 1 mod 3) and of step kt + 2; panel of kt + 4 (= kt mod 4)
-        int e_req = E_SLOT, e_dw = 2 * E_SLOT;
-        for (int kt = 0; kt < nst; ++kt) {
-            // own requests of step kt + 2 landed (one younger step may stay in flight), own LDS accesses done,
-            // then everyone's (one statement: nothing moves in between)
-            if (kt + 3 < nst) wait_all_but_youngest_step();
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (pr_bar) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            const bool do_req = kt + DIST < nst;
-            const int b_req = (kt & 3) * B_SLOT, b_frag = ((kt + 1) & 3) * B_SLOT;
-            char* a_dw = As + (kt & 1) * A_SLOT;                    // A tile of step kt + 2
-            const char* a_frag = As + ((kt + 1) & 1) * A_SLOT;
-            if (kt + 2 < nst && is_dw_wave(kt)) depthwise(Es + e_dw, a_dw);
-            multiply_half(0, do_req, e_req, b_req);
-            if (kt + 1 < nst) load_frag(a_frag, Bs + b_frag, 0);
-            multiply_half(1, do_req, e_req, b_req);
-            if (kt + 1 < nst) load_frag(a_frag, Bs + b_frag, 1);
-            e_req = e_req == 2 * E_SLOT ? 0 : e_req + E_SLOT;
-            e_dw = e_dw == 2 * E_SLOT ? 0 : e_dw + E_SLOT;
-        }
+        // rotating slot offsets: e[i] / a[i] = slot of step kt + i (mod 3), b[i] = panel of step kt + i (mod 5)
+        int e0 = 0, e1 = E_SLOT, e2 = 2 * E_SLOT;
+        int a0 = 0, a1 = A_SLOT, a2 = 2 * A_SLOT;
+        int b0 = 0, b1 = B_SLOT, b2 = 2 * B_SLOT, b3 = 3 * B_SLOT, b4 = 4 * B_SLOT;
+        int kt = 0;
+        auto rotate = [&]() {
+            int t = e0; e0 = e1; e1 = e2; e2 = t;
+            t = a0; a0 = a1; a1 = a2; a2 = t;
+            t = b0; b0 = b1; b1 = b2; b2 = b3; b3 = b4; b4 = t;
+            ++kt;
+        };
+        // (requests of step kt + 4: E slot (kt + 1) % 3, panel (kt + 4) % 5).  One role per wave: no per-request branches
+        auto k_loop = [&](auto role_dw, auto role_ld) {
+            for (; kt + DIST < nst; rotate()) k_step(std::true_type{}, role_dw, role_ld, kt, e1, b4, e2, a2, a1, b1);
+            for (; kt < nst; rotate()) k_step(std::false_type{}, role_dw, role_ld, kt, e1, b4, e2, a2, a1, b1);
+        };
+        k_loop(role_dw, role_ld);
         const bool has_next = tile + walk.stride < walk.end;
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave is past its LDS reads
         if (has_next) {
@@ -1334,6 +1357,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 1) void dwproj_f32_kernel(c
         }
         if (!has_next) break;
     }
+    };
+    if (NW == 4) run(std::true_type{}, std::true_type{});
+    else if (dw_wave) run(std::true_type{}, std::false_type{});
+    else run(std::false_type{}, std::true_type{});
 }
 
 // =====================================================================================
@@ -1725,13 +1752,13 @@ int launch_h16_dma(const ConvK& k0, int taps, hipStream_t stream) {
 bool dwproj_eligible(const uavsal_conv_desc* d) {
     static const bool on = [] { const char* e = getenv("UAVSAL_DWPROJ_LDS"); return !(e && e[0] == '0'); }();
     return on && d->dw_w9c && d->prec == UAVSAL_PREC_F32 && d->taps == 1 && d->dw_stride == 1 && d->Cin % 16 == 0 &&
-           d->epi == UAVSAL_EPI_AFFINE;
+           d->Cin <= UAVSAL_DWPROJ_MAX_C && d->epi == UAVSAL_EPI_AFFINE;
 }
 
 template <int WAVES_M, int WAVES_N, int WM, int WN>
 int launch_dwproj_variant(const ConvK& k0, hipStream_t stream) {
     constexpr int BN = WAVES_N * WN * 32, NT = WAVES_M * WAVES_N * 64;
-    constexpr int SMEM = 3 * (13 * 1024) + 4 * BN * 64 + 2 * 128 * 64;   // E slots, weight panels, A tiles
+    constexpr int SMEM = 3 * (13 * 1024) + 5 * BN * 64 + 3 * 128 * 64 + 1024;   // E slots, weight panels, A tiles, scratch
     ConvK k = k0;
     k.tiles_n = (k.Cout + BN - 1) / BN;
     k.nblk = (k.M / k.HW) * ((k.H + 7) / 8) * ((k.W + 15) / 16) * k.tiles_n;

@@ -80,8 +80,8 @@ if __name__ == "__main__":
         run(int(sys.argv[3]) if len(sys.argv) > 3 else 8, 45, 80, 1536, 256, int(sys.argv[2]), False)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "slope":      # per-K-step cost: same launch at three depths
-        for act in (0, 158, 134, 130):
-            for hid in (768, 1536, 3072):
+        for act in ((0, 158, 134, 130) if len(sys.argv) < 3 else (0,)):
+            for hid in (384, 768, 1536, 3072):
                 run(8, 45, 80, hid, 256, act, False)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "parts":      # library built with -DUAVSAL_PROBE
