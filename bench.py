@@ -145,7 +145,7 @@ def kernel_rooflines(eng, prec, iters=5):
         if m["kind"].startswith("conv"):
             key = kernel_symbol(prec, m["tile"], 9 if m["kind"] == "conv3" else 1, m.get("streamk", 0), m.get("split", False))
             if m.get("dwproj"):
-                key = "dwproj_f32_kernel<%s>" % {256: "2, 4, 2, 2", 128: "2, 4, 2, 1", 64: "4, 2, 1, 1", 32: "4, 1, 1, 1"}[m["dwproj"]]
+                key = "dwproj_kernel<%d, %s>" % (PREC_ID[prec], {256: "2, 4, 2, 2", 128: "2, 4, 2, 1", 64: "4, 2, 1, 1", 32: "4, 1, 1, 1"}[m["dwproj"]])
             elif m.get("fused_dw"):
                 key = "conv_gemm_kernel<%s, true>" % (H16_INST[m["tile"]] % (PREC_ID[prec], 1))
         elif m["kind"] in ("dw", "fused_ir"):
@@ -219,19 +219,19 @@ def fused_family(groups):
             "note": "unfused, the same seven blocks move %.0f MB per step" % (sum(g.get("unfused_bytes", 0.0) for g in fu.values()) / 1e6)}
 
 
-def dwproj_family(groups):
+def dwproj_family(groups, prec):
     """Depthwise -> projection launches with the LDS halo tile (the dwBlocks of the head / decoder): D never reaches
     HBM.  MFMA-bound (fp32 matrix peak) with the depthwise's FLOPs counted; fused-floor bytes (E read + output)
     beside it."""
-    fu = {k: g for k, g in groups.items() if k.startswith("dwproj_f32_kernel")}
+    fu = {k: g for k, g in groups.items() if k.startswith("dwproj_kernel")}
     if not fu:
         return None
     byts = sum(g["bytes"] for g in fu.values())
     ms = sum(g["ms"] for g in fu.values())
     fl = sum(g["flops"] for g in fu.values())
-    return {"kernel": "dwproj_f32_kernel (depthwise 3x3 + projection per launch, LDS halo)", "bound": "mfma",
-            "achieved": round(fl / ms / 1e9, 2), "peak": PEAK_TFLOPS["f32"], "unit": "TFLOP/s",
-            "frac": round(fl / ms / 1e9 / PEAK_TFLOPS["f32"], 4), "traffic": None,
+    return {"kernel": "dwproj_kernel (depthwise 3x3 + projection per launch, LDS halo)", "bound": "mfma",
+            "achieved": round(fl / ms / 1e9, 2), "peak": round(PEAK_TFLOPS[prec], 1), "unit": "TFLOP/s",
+            "frac": round(fl / ms / 1e9 / PEAK_TFLOPS[prec], 4), "traffic": None,
             "launches_per_step": sum(g["launches"] for g in fu.values()), "fused_floor_mb_per_step": round(byts / 1e6, 3),
             "kernel_ms_per_step": round(ms, 4), "hbm_gbs": round(byts / ms / 1e6, 1),
             "instances": {k: {"launches": g["launches"], "ms": round(g["ms"], 4)} for k, g in fu.items()}}
@@ -375,7 +375,7 @@ def main():
             if fus:
                 fus["share_of_kernel_time"] = round(fus["kernel_ms_per_step"] / tot, 3)
                 result["roofline_fused"] = fus
-            dwp = dwproj_family(groups)
+            dwp = dwproj_family(groups, args.prec)
             if dwp:
                 dwp["share_of_kernel_time"] = round(dwp["kernel_ms_per_step"] / tot, 3)
                 result["roofline_dwproj"] = dwp

@@ -231,7 +231,7 @@ __device__ __forceinline__ f32x4 prescale(f32x4 x) {
 // 16 bytes of zeros: what out-of-range lanes (M / K tails, 3x3 zero padding) fetch instead of
 // being masked off
 __device__ __attribute__((aligned(16))) float g_zero16[4];
-// zeros for a whole K walk (dwproj_f32_kernel: out-of-image halo pixels advance through it like real rows do)
+// zeros for a whole K walk (dwproj_kernel: out-of-image halo pixels advance through it like real rows do)
 #define UAVSAL_DWPROJ_MAX_C 4096
 __device__ __attribute__((aligned(16))) float g_zero_row[UAVSAL_DWPROJ_MAX_C + 16];
 
@@ -1037,9 +1037,17 @@ void conv_gemm_f32_dma_kernel(const ConvK p) {
 // One barrier per K step; E slots x3, weight panels x5, A tiles x3.  A-tile row r holds the pixel
 // (y, x) = (4 r5 + r[2:1], 8 r6 + 2 (r0 + 2 r4) + r3) (r_i = bit i of r), which makes the depthwise stores of a
 // lane group fall on distinct banks; the epilogue inverts it.
+// PREC = F16X3: the same walk with the split-fp16 product.  The depthwise phase writes the A tile as
+// [hi 16 halves | lo 16 halves] per row (hi = fp16_rtz(16 d), lo = fp16_rtz(16 d - hi): the split-shadow values), the
+// weight panel arrives pre-split the same way ('f16x3j': [Cin/16][Npad][hi 16 | lo 16]), and a K step is
+// lo*hi + hi*lo + hi*hi on v_mfma_f32_32x32x16_f16 -- 12 instead of 32 MFMA issues per wave, so these launches are
+// bound by the requests (29 KB per step and workgroup), not by the matrix pipe.  All fragments of the next step are
+// read after the last MFMA and stay in flight across the barrier.
 // Shapes: stride 1, dilation 1, hidden channels % 16 == 0 (host: dwproj_eligible).
-template <int WAVES_M, int WAVES_N, int WM, int WN>
-__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 1) void dwproj_f32_kernel(const ConvK p) {
+template <int PREC, int WAVES_M, int WAVES_N, int WM, int WN>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 1) void dwproj_kernel(const ConvK p) {
+    static_assert(PREC == UAVSAL_PREC_F32 || PREC == UAVSAL_PREC_F16X3, "fp32 or split-fp16");
+    constexpr bool H16 = PREC == UAVSAL_PREC_F16X3;
     constexpr int PH = 8, PW = 16, HPITCH = PW + 3, NHSLOT = (PH + 2) * HPITCH;
     constexpr int BM = PH * PW, BN = WAVES_N * WN * 32;
     constexpr int NW = WAVES_M * WAVES_N, NT = NW * 64;
@@ -1052,7 +1060,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 1) void dwproj_f32_kernel(c
     constexpr int NLW = 4;                            // waves that issue the requests: the second wave of each SIMD (8-wave
                                                       // instances; the first one runs the depthwise), else all four
     constexpr int E_IT = (E_REQ + 1 + NLW - 1) / NLW, B_IT = (B_REQ + NLW - 1) / NLW, NREQ = E_IT + B_IT;
-    constexpr int NGRP = 2 * WM * WN, RPG = (NREQ + NGRP - 1) / NGRP;
+    constexpr int NGRP = (H16 ? 1 : 2) * WM * WN, RPG = (NREQ + NGRP - 1) / NGRP;
+    constexpr int NTAIL = (H16 ? 2 : 1) * (WM + WN);   // fragment reads issued after a step's last MFMA
     constexpr int DW_ITEMS = BM * 4 / 2 / 64;         // waves' worth of (1 x 2 strip, 4 channels) items: 4
     static_assert(WAVES_M * WM * 32 == BM, "the M tile is the 8 x 16 patch");
     static_assert(2 * B_SLOT >= 32 * BN * 4, "epilogue staging = two weight panels");
@@ -1073,6 +1082,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 1) void dwproj_f32_kernel(c
     const int lr = lane & 31, lh = lane >> 5;
     const int pwn = (p.W + PW - 1) / PW, phn = (p.H + PH - 1) / PH;
     const int nst = p.Cin / KT;
+    const int b_adv = p.Npad * 64;                     // F16X3: bytes between the weight panels of two K steps
 
     const uavsal_tile_walk walk = xcd_tile_walk(blockIdx.x, gridDim.x, p.nblk);
     int tile = walk.tile;
@@ -1121,8 +1131,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 1) void dwproj_f32_kernel(c
                 const int q = lw + (r - E_IT) * NLW;
                 const int row = q * 16 + (lane >> 2);
                 const int lc = (lane & 3) ^ ((row >> 2) & 3);
-                const int nn = n0 + row;
-                if (q < B_REQ && nn < p.Npad) src = reinterpret_cast<const float*>(p.w) + (size_t)nn * p.Kpad + lc * 4;
+                // rows past Npad (and the spare requests) fetch the last real row: a lane of a weight request must never
+                // walk the zero row, its per-step advance is a whole panel (F16X3); those columns are never stored
+                const int nn = min(n0 + row, p.Npad - 1);
+                src = H16 ? reinterpret_cast<const float*>(p.w + (size_t)nn * 64) + lc * 4       // [step][Npad][64 B]
+                          : reinterpret_cast<const float*>(p.w) + (size_t)nn * p.Kpad + lc * 4;
             }
             rq_ptr[r] = reinterpret_cast<const char*>(src ? src : g_zero_row + ck);
         }
@@ -1140,7 +1153,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 1) void dwproj_f32_kernel(c
         if (!pr_dma) return;
         char* dst = rq_lds[r] < 0 ? Scratch : (r < E_IT ? Es + eo : Bs + bo) + rq_lds[r];
         __builtin_amdgcn_global_load_lds((gptr_t)rq_ptr[r], (lptr_t)dst, 16, 0, 0);
-        rq_ptr[r] += KT * 4;
+        rq_ptr[r] += (H16 && r >= E_IT) ? b_adv : KT * 4;
     };
     auto issue_all = [&](int eo, int bo) {
         if (!loader) return;
@@ -1182,7 +1195,15 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 1) void dwproj_f32_kernel(c
             d.z = __builtin_amdgcn_fmed3f(fmaf(o[j].z, sc.z, bi.z), 0.f, 6.f);
             d.w = __builtin_amdgcn_fmed3f(fmaf(o[j].w, sc.w, bi.w), 0.f, 6.f);
             const int rho = (sx2 & 1) + 2 * syl + 8 * j + 16 * (sx2 >> 1) + 32 * half + 64 * xh;
-            *reinterpret_cast<f32x4*>(at + (rho * 4 + (cq ^ ((rho >> 2) & 3))) * 16) = d;
+            if (H16) {       // row = [hi k 0-7 | hi k 8-15 | lo k 0-7 | lo k 8-15], 16-byte chunks swizzled like the fp32 row
+                u32x2 hi, lo;
+                uavsal_split4_f16(d, hi, lo);
+                const int sw = (rho >> 2) & 3;
+                *reinterpret_cast<u32x2*>(at + (rho * 4 + ((cq >> 1) ^ sw)) * 16 + (cq & 1) * 8) = hi;
+                *reinterpret_cast<u32x2*>(at + (rho * 4 + ((2 + (cq >> 1)) ^ sw)) * 16 + (cq & 1) * 8) = lo;
+            } else {
+                *reinterpret_cast<f32x4*>(at + (rho * 4 + (cq ^ ((rho >> 2) & 3))) * 16) = d;
+            }
         }
         __builtin_amdgcn_s_setprio(0);
     };
@@ -1206,18 +1227,27 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 1) void dwproj_f32_kernel(c
             bfr[u][j] = *reinterpret_cast<const f32x4*>(bt + (row * 4 + (chunk ^ ((row >> 2) & 3))) * 16);
         }
     };
-    // half u of the K step's MFMAs; a loader wave's requests for the step four ahead are slotted behind the groups
+    // half u of the K step's MFMAs (F16X3: u = 0 is the whole step: fragment set 0 holds the hi, set 1 the lo halves);
+    // a loader wave's requests for the step four ahead are slotted behind the groups
     auto multiply_half = [&](auto with_req, int u, int eo, int bo) {
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
             for (int j = 0; j < WN; ++j) {
                 if (pr_mul) {
-                    const f32x4 av = af[u][i], bv = bfr[u][j];
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[i][j], 0, 0, 0);
+                    if (H16) {
+                        const f16x8 ah = __builtin_bit_cast(f16x8, af[0][i]), al = __builtin_bit_cast(f16x8, af[1][i]);
+                        const f16x8 bh = __builtin_bit_cast(f16x8, bfr[0][j]), bl = __builtin_bit_cast(f16x8, bfr[1][j]);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[i][j], 0, 0, 0);
+                    } else {
+                        const f32x4 av = af[u][i], bv = bfr[u][j];
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[i][j], 0, 0, 0);
+                    }
                 }
                 if (decltype(with_req)::value) {
                     const int grp = (u * WM + i) * WN + j;
@@ -1240,19 +1270,20 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 1) void dwproj_f32_kernel(c
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         if (pr_bar) {
-            if (FULL || kt + 1 < nst) asm volatile("s_waitcnt lgkmcnt(%0)\n\ts_barrier" :: "n"(WM + WN) : "memory");
+            if (FULL || kt + 1 < nst) asm volatile("s_waitcnt lgkmcnt(%0)\n\ts_barrier" :: "n"(NTAIL) : "memory");
             else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
         if (DW && pr_dw && (FULL || kt + 2 < nst)) depthwise(Es + eo_dw, As + ao_dw);
         if (LD && (FULL || kt + DIST < nst)) {
             multiply_half(std::true_type{}, 0, eo_req, bo_req);
-            if (FULL || kt + 1 < nst) load_frag(As + ao_frag, Bs + bo_frag, 0);
-            multiply_half(std::true_type{}, 1, eo_req, bo_req);
+            if (H16 ? false : (FULL || kt + 1 < nst)) load_frag(As + ao_frag, Bs + bo_frag, 0);
+            if (!H16) multiply_half(std::true_type{}, 1, eo_req, bo_req);
         } else {
             multiply_half(std::false_type{}, 0, 0, 0);
-            if (FULL || kt + 1 < nst) load_frag(As + ao_frag, Bs + bo_frag, 0);
-            multiply_half(std::false_type{}, 1, 0, 0);
+            if (H16 ? false : (FULL || kt + 1 < nst)) load_frag(As + ao_frag, Bs + bo_frag, 0);
+            if (!H16) multiply_half(std::false_type{}, 1, 0, 0);
         }
+        if (H16 && (FULL || kt + 1 < nst)) load_frag(As + ao_frag, Bs + bo_frag, 0);
         if (FULL || kt + 1 < nst) load_frag(As + ao_frag, Bs + bo_frag, 1);
     };
 
@@ -1311,7 +1342,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 1) void dwproj_f32_kernel(c
             for (int j = 0; j < WN; ++j) {
                 const int c = cn0 + (wn * WN + j) * 32 + lr;
                 const bool okn = p.scale != nullptr && c < p.Cout;
-                sc[j] = okn ? p.scale[c] : 1.f;
+                sc[j] = (okn ? p.scale[c] : 1.f) * (H16 ? F16X3_ACC_SCALE : 1.f);
                 bi[j] = okn ? p.bias[c] : 0.f;
             }
 #pragma unroll
@@ -1345,6 +1376,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 1) void dwproj_f32_kernel(c
                             if (vec) {
                                 if (rs) v += *reinterpret_cast<const f32x4*>(rs);
                                 *reinterpret_cast<f32x4*>(o) = v;
+                                if (H16 && p.out_sp)     // split shadow for the GEMM that consumes this output
+                                    uavsal_store_split4(p.out_sp + ((long long)cimg * p.o_is + pix) * p.ldos, gn, v);
                             } else {
 #pragma unroll
                                 for (int c = 0; c < 4; ++c)
@@ -1748,14 +1781,14 @@ int launch_h16_dma(const ConvK& k0, int taps, hipStream_t stream) {
     return uavsal_launch_status();
 }
 
-// LDS-halo depthwise -> projection (fp32): which descriptors take it, and the launch
+// LDS-halo depthwise -> projection (fp32 / split-fp16): which descriptors take it, and the launch
 bool dwproj_eligible(const uavsal_conv_desc* d) {
     static const bool on = [] { const char* e = getenv("UAVSAL_DWPROJ_LDS"); return !(e && e[0] == '0'); }();
-    return on && d->dw_w9c && d->prec == UAVSAL_PREC_F32 && d->taps == 1 && d->dw_stride == 1 && d->Cin % 16 == 0 &&
-           d->Cin <= UAVSAL_DWPROJ_MAX_C && d->epi == UAVSAL_EPI_AFFINE;
+    return on && d->dw_w9c && (d->prec == UAVSAL_PREC_F32 || d->prec == UAVSAL_PREC_F16X3) && d->taps == 1 &&
+           d->dw_stride == 1 && d->Cin % 16 == 0 && d->Cin <= UAVSAL_DWPROJ_MAX_C && d->epi == UAVSAL_EPI_AFFINE;
 }
 
-template <int WAVES_M, int WAVES_N, int WM, int WN>
+template <int PREC, int WAVES_M, int WAVES_N, int WM, int WN>
 int launch_dwproj_variant(const ConvK& k0, hipStream_t stream) {
     constexpr int BN = WAVES_N * WN * 32, NT = WAVES_M * WAVES_N * 64;
     constexpr int SMEM = 3 * (13 * 1024) + 5 * BN * 64 + 3 * 128 * 64 + 1024;   // E slots, weight panels, A tiles, scratch
@@ -1763,20 +1796,21 @@ int launch_dwproj_variant(const ConvK& k0, hipStream_t stream) {
     k.tiles_n = (k.Cout + BN - 1) / BN;
     k.nblk = (k.M / k.HW) * ((k.H + 7) / 8) * ((k.W + 15) / 16) * k.tiles_n;
     static const int cap = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwproj_f32_kernel<WAVES_M, WAVES_N, WM, WN>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwproj_kernel<PREC, WAVES_M, WAVES_N, WM, WN>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-        return resident_grid(dwproj_f32_kernel<WAVES_M, WAVES_N, WM, WN>, SMEM, NT);
+        return resident_grid(dwproj_kernel<PREC, WAVES_M, WAVES_N, WM, WN>, SMEM, NT);
     }();
     const int grid = k.nblk < cap ? k.nblk : cap;
-    hipLaunchKernelGGL((dwproj_f32_kernel<WAVES_M, WAVES_N, WM, WN>), dim3(grid), dim3(NT), SMEM, stream, k);
+    hipLaunchKernelGGL((dwproj_kernel<PREC, WAVES_M, WAVES_N, WM, WN>), dim3(grid), dim3(NT), SMEM, stream, k);
     return uavsal_launch_status();
 }
 
+template <int PREC>
 int launch_dwproj(const ConvK& k, hipStream_t stream) {
-    if (k.Cout > 128) return launch_dwproj_variant<2, 4, 2, 2>(k, stream);   // 128 x 256, 8 waves
-    if (k.Cout > 64) return launch_dwproj_variant<2, 4, 2, 1>(k, stream);    // 128 x 128, 8 waves
-    if (k.Cout > 32) return launch_dwproj_variant<4, 2, 1, 1>(k, stream);    // 128 x 64,  8 waves
-    return launch_dwproj_variant<4, 1, 1, 1>(k, stream);                     // 128 x 32,  4 waves
+    if (k.Cout > 128) return launch_dwproj_variant<PREC, 2, 4, 2, 2>(k, stream);   // 128 x 256, 8 waves
+    if (k.Cout > 64) return launch_dwproj_variant<PREC, 2, 4, 2, 1>(k, stream);    // 128 x 128, 8 waves
+    if (k.Cout > 32) return launch_dwproj_variant<PREC, 4, 2, 1, 1>(k, stream);    // 128 x 64,  8 waves
+    return launch_dwproj_variant<PREC, 4, 1, 1, 1>(k, stream);                     // 128 x 32,  4 waves
 }
 
 // pre-split path: 256 x 256 / 128 x 256 on 8 waves, 128 x 128 on 4 (two workgroups per CU)
@@ -1976,7 +2010,8 @@ extern "C" int uavsal_conv_gemm(const uavsal_conv_desc* d, uavsal_stream_t strea
     k.a_sp = (const _Float16*)d->a_split; k.ldas = d->ldas;
     k.out_sp = (_Float16*)d->out_split; k.ldos = d->ldos;
     if (split_eligible(d, tile)) return launch_h16(k, d->taps, tile, s);
-    if (dwproj_eligible(d)) return launch_dwproj(k, s);
+    if (dwproj_eligible(d))
+        return d->prec == UAVSAL_PREC_F32 ? launch_dwproj<UAVSAL_PREC_F32>(k, s) : launch_dwproj<UAVSAL_PREC_F16X3>(k, s);
     if (!d->a) return UAVSAL_EINVAL;             // pre-split operands given but the shape is not eligible
     {
         const int G = streamk_plan(d, tile, k.ktiles);

@@ -92,7 +92,7 @@ class Engine:
         self._err = None
         self._sk_debug = tuple(getattr(model, "_sk_debug", (0, 0)))
         # fused depthwise->projection GEMM (uavsal_conv_desc.dw_*): D never reaches HBM.
-        #   None (default): the fp32 LDS-halo kernel (dwproj_f32_kernel) on the blocks where it wins -- stride 1,
+        #   None (default): the LDS-halo kernel (dwproj_kernel, fp32 and f16x3) on the blocks where it wins -- stride 1,
         #     dilation 1, hidden % 16 == 0 and at least FUSE_DW_MIN_WORK expanded values (the 45x80 / 90x160 dwBlocks
         #     of the head and the decoder: profiles/r2_dwproj.md); other precisions keep the three-launch form;
         #   True: every dilation-1 block with an expand conv (strides 2 and the 16-bit precisions then run the
@@ -240,9 +240,10 @@ class Engine:
             self._wcache[key] = (self._dev(P.pad_vec(s, n, 1.0)), self._dev(P.pad_vec(b, n, 0.0)))
         return self._wcache[key]
 
-    def _convw(self, conv, sl=None, gate_interleave=0, natural=False):
-        """`natural`: the pre-split LDS-DMA path takes the weights as [K step][Cout][hi 32 | lo 32] ('f16x3i')."""
-        layout = "f16x3i" if natural else self.prec_name
+    def _convw(self, conv, sl=None, gate_interleave=0, natural=False, dwproj=False):
+        """`natural`: the pre-split LDS-DMA path takes the weights as [K step][Cout][hi 32 | lo 32] ('f16x3i');
+        `dwproj`: the split-fp16 depthwise -> projection kernel takes [K step of 16][Cout][hi 16 | lo 16] ('f16x3j')."""
+        layout = "f16x3i" if natural else ("f16x3j" if dwproj and self.prec_name == "f16x3" else self.prec_name)
         key = ("w", id(conv), sl, layout, gate_interleave)
         if key not in self._wcache:
             w = conv.weight.detach()
@@ -358,11 +359,12 @@ class Engine:
         split = int(self.lib.uavsal_conv_uses_split(C.byref(d))) == 1
         if a.t is None and not split:
             raise RuntimeError("%s: its input only exists as a split shadow but the GEMM is not eligible" % name)
-        d.w = self._convw(conv, wslice, gate_interleave, natural=split).data_ptr()
+        dwproj = int(self.lib.uavsal_conv_dwproj(C.byref(d)))
+        d.w = self._convw(conv, wslice, gate_interleave, natural=split, dwproj=dwproj != 0).data_ptr()
         self.ops_meta[-1]["split"] = split
         self.ops_meta[-1]["tile"] = int(self.lib.uavsal_conv_tile(C.byref(d)))
         self.ops_meta[-1]["streamk"] = int(self.lib.uavsal_conv_streamk_grid(C.byref(d)))
-        self.ops_meta[-1]["dwproj"] = int(self.lib.uavsal_conv_dwproj(C.byref(d)))
+        self.ops_meta[-1]["dwproj"] = dwproj
         self._add(self.lib.uavsal_plan_add_conv, d, "plan_add_conv(%s)" % name)
 
     def dw(self, name, a: V, conv, bn, out: V, stride, dilation):
@@ -481,7 +483,7 @@ class Engine:
             dwc, dwbn, pl, plbn = seq[0][0], seq[0][1], seq[1], seq[2]
         ho, wo = (x.h - 1) // stride + 1, (x.w - 1) // stride + 1
         if dil == 1 and blk.expand_ratio != 1 and (self.fuse_dw or (
-                self.fuse_dw is None and self.prec_name == "f32" and stride == 1 and blk.hidden % 16 == 0
+                self.fuse_dw is None and self.prec_name in ("f32", "f16x3") and stride == 1 and blk.hidden % 16 == 0
                 and x.n * x.h * x.w * blk.hidden >= FUSE_DW_MIN_WORK)):
             # depthwise computed inside the projection GEMM's loader: D never reaches HBM
             self.conv(name + ".dwpl", e, pl, plbn, out, final_act, res=x if blk.use_res_connect else None,

@@ -121,7 +121,8 @@ def conv_gemm(x, weight, scale=None, bias=None, act=L.ACT_NONE, res=None, out=No
     uses_split = int(lib.uavsal_conv_uses_split(C.byref(d))) == 1
     if split_in and not uses_split:
         raise RuntimeError("this shape / tile does not take the pre-split path")
-    wp = P.pack_conv_weight(weight, "f16x3i" if uses_split else prec).to(x.device)
+    dwproj = int(lib.uavsal_conv_dwproj(C.byref(d))) != 0
+    wp = P.pack_conv_weight(weight, "f16x3i" if uses_split else ("f16x3j" if dwproj and prec == "f16x3" else prec)).to(x.device)
     keep.append(wp)
     d.w = wp.data_ptr()
     L.check(lib.uavsal_conv_gemm(C.byref(d), _stream(x)), "uavsal_conv_gemm")

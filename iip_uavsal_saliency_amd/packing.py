@@ -38,12 +38,12 @@ def pack_conv_weight(w: torch.Tensor, prec: str) -> torch.Tensor:
     """`w` [Cout, Cin, kh, kw] (kh=kw in {1,3}) -> packed byte tensor (uint8, 1-D) in the layout
     `uavsal_conv_gemm` expects for `prec` in {'f32','bf16','bf16x3','f16x3'}, or 'f16x3i': the f16x3
     values with the natural k order, hi and lo of one (K step, output channel) interleaved into one 128-byte
-    line [Kpad/32][Npad][hi 32 | lo 32] (the pre-split LDS-DMA path, uavsal_conv_uses_split)."""
+    line [Kpad/32][Npad][hi 32 | lo 32] (the pre-split LDS-DMA path, uavsal_conv_uses_split), or 'f16x3j' (below)."""
     w = w.detach().float().cpu()
     cout, cin, kh, kw = w.shape
     taps = kh * kw
     assert taps in (1, 9) and kh == kw
-    kt = 16 if prec == "f32" else 32
+    kt = 16 if prec == "f32" else 32            # ('f16x3j' pads K to 32 too: the kernel walks Cin / 16 steps of it)
     if taps == 9 and cin % 32:
         raise RuntimeError("3x3 dense conv needs Cin % 32 == 0")
     k = taps * cin
@@ -59,6 +59,13 @@ def pack_conv_weight(w: torch.Tensor, prec: str) -> torch.Tensor:
         m[:cout, :k] = w.reshape(cout, cin // kt, kt, 9).permute(0, 1, 3, 2).reshape(cout, k)
     if prec == "f32":
         return m.contiguous().view(torch.uint8).reshape(-1)
+    if prec == "f16x3j":    # LDS-halo depthwise -> projection kernel (uavsal_conv_dwproj): K steps of 16 channels,
+        # natural k order, one 64-byte line [hi 16 | lo 16] per (K step, output channel): [Kpad/16][Npad][2][16]
+        assert taps == 1
+        mm = m.view(npad, kpad // 16, 16) * 64.0
+        hi = mm.to(torch.float16)
+        lo = (mm - hi.float()).to(torch.float16)
+        return torch.stack([hi, lo], 2).permute(1, 0, 2, 3).contiguous().view(torch.uint8).reshape(-1)
     # 16-bit layouts are K-step-major: [Kpad/32][panel][Npad][32] -- one K step is one contiguous run
     idx = torch.tensor(list(range(32)) if prec == "f16x3i" else _K_PERM32, dtype=torch.long)
     m = m.view(npad, kpad // 32, 32)[:, :, idx]                 # [npad, steps, 32]

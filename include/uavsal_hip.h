@@ -125,9 +125,10 @@ typedef struct uavsal_conv_desc {
      * groups=hidden BasicConv2d of dwBlock (model.py:92) feeding its pw-linear conv (model.py:94) without the
      * intermediate tensor ever reaching HBM.  H, W are the OUTPUT sizes ((dw_Hin-1)/dw_stride+1, ...);
      * dw_w9c is tap-major [9][Cin] as in uavsal_dw_desc; a_img_stride counts input pixels.
-     * F32, dw_stride 1, Cin % 16 == 0 run the LDS-halo kernel (a workgroup stages the 10 x 18 halo of an 8 x 16
-     * pixel patch per 16 channels, computes the depthwise in LDS and feeds the fp32 MFMA loop: uavsal_conv_dwproj
-     * tells); everything else the register-staged loader of round 1 (correct, latency-bound). */
+     * F32 / F16X3, dw_stride 1, Cin % 16 == 0 (<= 4096) run the LDS-halo kernel (a workgroup stages the 10 x 18
+     * halo of an 8 x 16 pixel patch per 16 channels, computes the depthwise in LDS and feeds the MFMA loop:
+     * uavsal_conv_dwproj tells; its F16X3 form takes the weights as [Cin/16][Npad][hi 16 | lo 16] fp16 lines of
+     * 64 w, packing.py 'f16x3j'); everything else the register-staged loader of round 1 (correct, latency-bound). */
     const float* dw_w9c; const float* dw_scale; const float* dw_bias;
     int32_t dw_stride, dw_Hin, dw_Win;
     /* Optional stream-K workspace (fp32, 128x128 and 64x64 tiles; 64 KB of flags, then partial tiles): `uavsal_streamk_workspace_bytes()` bytes of device
@@ -169,7 +170,7 @@ int uavsal_conv_tile(const uavsal_conv_desc* d);
  * eligible) and therefore expects `w` in the 'f16x3i' packing, else 0; no launch */
 int uavsal_conv_uses_split(const uavsal_conv_desc* d);
 /* 0, or the LDS-halo depthwise -> projection instance this descriptor launches (no launch): its output-channel
- * tile 256 / 128 / 64 / 32 = dwproj_f32_kernel<2,4,2,2> / <2,4,2,1> / <4,2,1,1> / <4,1,1,1> */
+ * tile 256 / 128 / 64 / 32 = dwproj_kernel<PREC,2,4,2,2> / <PREC,2,4,2,1> / <PREC,4,2,1,1> / <PREC,4,1,1,1> */
 int uavsal_conv_dwproj(const uavsal_conv_desc* d);
 /* size of the optional stream-K workspace (see uavsal_conv_desc.sk_ws) */
 long long uavsal_streamk_workspace_bytes(void);

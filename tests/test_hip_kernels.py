@@ -267,7 +267,7 @@ def test_fused_depthwise_projection(ops, prec, case):
     assert err <= TOL[prec] * 8.0, (case, prec, err)
 
 
-# LDS-halo depthwise -> projection kernel (dwproj_f32_kernel): every instance (output tile 256 / 128 / 64 / 32), maps
+# LDS-halo depthwise -> projection kernel (dwproj_kernel, fp32 and split-fp16): every instance (output tile 256 / 128 / 64 / 32), maps
 # that are not multiples of the 8 x 16 patch, one row / one column maps, several images (tile walk), residual,
 # sigmoid + Cout = 1 (scalar store path: the decoder's last launch), output / residual as channel slices
 DWPROJ_CASES = [
@@ -279,8 +279,9 @@ DWPROJ_CASES = [
 ]
 
 
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
 @pytest.mark.parametrize("case", DWPROJ_CASES)
-def test_depthwise_projection_lds_halo(ops, case):
+def test_depthwise_projection_lds_halo(ops, case, prec):
     """dwBlock tail (model.py:92-95) in one launch with the halo tile in LDS == the two convs in fp32 torch."""
     from iip_uavsal_saliency_amd import _lib as L
     import ctypes as C
@@ -297,7 +298,7 @@ def test_depthwise_projection_lds_halo(ops, case):
     if use_res:
         ref = ref + res
     d = L.ConvDesc()
-    d.n_img, d.H, d.W, d.Cin, d.Cout, d.taps, d.prec, d.epi = n, h, w, c, cout, 1, L.PREC["f32"], L.EPI_AFFINE
+    d.n_img, d.H, d.W, d.Cin, d.Cout, d.taps, d.prec, d.epi = n, h, w, c, cout, 1, L.PREC[prec], L.EPI_AFFINE
     d.dw_w9c, d.dw_stride, d.out = 1 << 20, 1, 1 << 20
     inst = int(L.load().uavsal_conv_dwproj(C.byref(d)))
     assert inst == (256 if cout > 128 else 128 if cout > 64 else 64 if cout > 32 else 32)
@@ -310,11 +311,21 @@ def test_depthwise_projection_lds_halo(ops, case):
         rbuf = torch.zeros((n, h, w, cout + 2 * pad), device=dev)
         rbuf[..., pad:pad + cout] = nhwc(res)
     got = ops.conv_gemm(nhwc(e), wp, sp, bp, act=act, res=rbuf[..., pad:pad + cout] if use_res else None, out=out,
-                        prec="f32", dw=(wd, sd, bd, 1))
+                        prec=prec, dw=(wd, sd, bd, 1))
     err = (nchw(got.contiguous()) - ref).abs().max().item()
-    assert err <= 2e-5 * max(1.0, ref.abs().max().item()), (case, err)
+    assert err <= (2e-5 if prec == "f32" else TOL[prec]) * max(1.0, ref.abs().max().item()), (case, prec, err)
     if sliced:                          # nothing outside the slice was written
         assert (outbuf[..., :pad] == 7.0).all() and (outbuf[..., pad + cout:] == 7.0).all()
+
+
+def test_depthwise_projection_split_shadow(ops):
+    """f16x3: the fused launch also writes the split shadow of its output (what the next GEMM stages by LDS-DMA)."""
+    n, h, w, c, cout = 2, 19, 35, 96, 128
+    e = rnd((n, c, h, w), 261, 3.0).clamp(0, 6)
+    wd, sd, bd = rnd((c, 1, 3, 3), 262, 0.4), rnd((c,), 263) * 0.5 + 1.0, rnd((c,), 264)
+    wp, sp, bp = rnd((cout, c, 1, 1), 265, 1.0 / np.sqrt(c)), rnd((cout,), 266) * 0.5 + 1.0, rnd((cout,), 267)
+    out, shadow = ops.conv_gemm(nhwc(e), wp, sp, bp, prec="f16x3", dw=(wd, sd, bd, 1), split_out=True)
+    assert (ops.merge_shadow(shadow) - out).abs().max().item() <= 3.0 * 2 ** -20 * max(1.0, out.abs().max().item())
 
 
 DW_CASES = [

@@ -23,7 +23,7 @@ def time_plan(adders, iters=20):
     return ms.value * 1e3
 
 
-def run(n_img, h, w, hid, cout, act=0, use_res=False, stream_k=True):
+def run(n_img, h, w, hid, cout, act=0, use_res=False, stream_k=True, prec="f32"):
     g = torch.Generator().manual_seed(5)
     e = (torch.rand((n_img, h, w, hid), generator=g) * 6).to(dev)
     wd = ((torch.rand((hid, 1, 3, 3), generator=g) - 0.5) * 0.8)
@@ -34,7 +34,8 @@ def run(n_img, h, w, hid, cout, act=0, use_res=False, stream_k=True):
     b = (torch.rand(npad, generator=g) - 0.5).to(dev)
     res = torch.rand((n_img, h, w, cout), generator=g).to(dev) if use_res else None
     w9 = P.pack_dw_weight(wd).to(dev)
-    wpk = P.pack_conv_weight(wp, "f32").to(dev)
+    wpk = P.pack_conv_weight(wp, prec).to(dev)
+    wpj = P.pack_conv_weight(wp, "f16x3j").to(dev) if prec == "f16x3" else wpk
     dmid = torch.empty((n_img, h, w, hid), device=dev)
     out_a = torch.zeros((n_img, h, w, cout), device=dev)
     out_b = torch.zeros((n_img, h, w, cout), device=dev)
@@ -48,13 +49,13 @@ def run(n_img, h, w, hid, cout, act=0, use_res=False, stream_k=True):
     def conv_desc(a, out, fused):
         d = L.ConvDesc()
         d.a, d.lda, d.a_img_stride = a.data_ptr(), hid, h * w
-        d.w = wpk.data_ptr()
+        d.w = wpj.data_ptr() if fused else wpk.data_ptr()
         d.scale, d.bias = s.data_ptr(), b.data_ptr()
         d.out, d.ldc, d.o_img_stride = out.data_ptr(), cout, h * w
         if res is not None:
             d.res, d.ldr, d.r_img_stride = res.data_ptr(), cout, h * w
         d.n_img, d.H, d.W, d.Cin, d.Cout, d.taps = n_img, h, w, hid, cout, 1
-        d.prec, d.act, d.epi, d.tile = L.PREC["f32"], act, L.EPI_AFFINE, 0
+        d.prec, d.act, d.epi, d.tile = L.PREC[prec], act, L.EPI_AFFINE, 0
         if fused:
             d.dw_w9c, d.dw_scale, d.dw_bias = w9.data_ptr(), sd.data_ptr(), bd.data_ptr()
             d.dw_stride, d.dw_Hin, d.dw_Win = 1, h, w
@@ -69,8 +70,8 @@ def run(n_img, h, w, hid, cout, act=0, use_res=False, stream_k=True):
     torch.cuda.synchronize()
     err = (out_a - out_b).abs().max().item()
     fl = 2.0 * n_img * h * w * hid * cout
-    print("n=%d %dx%d hid=%d cout=%d act=%d res=%d: dw %.1f + pl %.1f = %.1f us | fused %.1f us (%.1f TFLOP/s, %.0f GB/s of E) | max diff %.2e"
-          % (n_img, h, w, hid, cout, act, use_res, t_dw, t_pl, t_dw + t_pl, t_f, fl / t_f / 1e6,
+    print("%s n=%d %dx%d hid=%d cout=%d act=%d res=%d: dw %.1f + pl %.1f = %.1f us | fused %.1f us (%.1f TFLOP/s, %.0f GB/s of E) | max diff %.2e"
+          % (prec, n_img, h, w, hid, cout, act, use_res, t_dw, t_pl, t_dw + t_pl, t_f, fl / t_f / 1e6,
              4.0 * n_img * h * w * hid / t_f / 1e3, err), flush=True)
     return err
 
@@ -96,5 +97,8 @@ if __name__ == "__main__":
                (8, 45, 80, 1152, 64, 0, False), (64, 45, 80, 1536, 256, 0, True), (2, 23, 41, 96, 128, 1, False),
                (1, 9, 13, 48, 24, 0, False), (32, 90, 160, 1536, 256, 0, False)]:
         worst = max(worst, run(*sh))
+    for sh in [(8, 45, 80, 1536, 256, 0, True), (8, 45, 80, 1536, 1, 2, False), (8, 45, 80, 1152, 64, 0, False),
+               (64, 45, 80, 1536, 256, 0, True), (2, 23, 41, 96, 128, 1, False)]:
+        worst = max(worst, 0.01 * run(*sh, prec="f16x3"))        # (f16x3 vs f16x3: ~1e-4 apart)
     print("worst diff %.2e" % worst)
     sys.exit(0 if worst < 2e-3 else 1)
