@@ -378,6 +378,9 @@ def main():
             dwp = dwproj_family(groups, args.prec)
             if dwp:
                 dwp["share_of_kernel_time"] = round(dwp["kernel_ms_per_step"] / tot, 3)
+                for inst, rec in dwp["instances"].items():       # measured HBM bytes per launch beside the fused-floor bytes
+                    rec["traffic"], _ = measured_traffic(inst, C, T, H, W, args.prec)
+                    rec["fused_floor_mb_per_launch"] = round(groups[inst]["bytes"] / groups[inst]["launches"] / 1e6, 3)
                 result["roofline_dwproj"] = dwp
             result["kernel_time_ms"] = {k: round(v["ms"], 4) for k, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])}
             result["stage_time_ms"] = {k: round(eng.time_ops(a, b, 5), 4) for k, (a, b) in eng.stage_ranges.items()}

@@ -39,5 +39,5 @@ out["__stamp__"] = {"kernel_sources_sha16": h.hexdigest()[:16], "workload": "pyt
                     "collected": datetime.date.today().isoformat()}
 json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
 for k, v in out.items():
-    if k != "__stamp__" and ("conv_gemm" in k or "dw3x3" in k):
+    if k != "__stamp__" and ("conv_gemm" in k or "dw3x3" in k or "dwproj" in k or "fused_ir" in k):
         print("%-60s n=%4d fetch %9.2f MB write %9.2f MB" % (k[:60], v["launches"], v["fetch_mb_per_launch_corrected"], v["write_mb_per_launch"]))
