@@ -318,6 +318,37 @@ def test_depthwise_projection_lds_halo(ops, case, prec):
         assert (outbuf[..., :pad] == 7.0).all() and (outbuf[..., pad + cout:] == 7.0).all()
 
 
+def _dwproj_fuzz_cases():
+    """Seeded random shapes: K walks of 1..7 steps (lead-in / tail conditions of the pipelined loop), output widths that
+    leave a partial last tile or a weight panel narrower than the tile, odd maps, several images."""
+    g = np.random.RandomState(7)
+    cases = []
+    for i in range(16):
+        hid = 16 * int(g.choice([1, 2, 3, 4, 5, 6, 7, 12]))
+        cout = int(g.choice([1, 3, 17, 32, 33, 64, 65, 100, 129, 200, 257, 320]))
+        cases.append((int(g.randint(1, 4)), int(g.randint(1, 30)), int(g.randint(1, 40)), hid, cout, int(g.randint(0, 3)),
+                      bool(g.randint(0, 2))))
+    return cases + [(1, 9, 9, 48, 200, 0, False), (1, 9, 9, 48, 257, 0, True)]
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+@pytest.mark.parametrize("case", _dwproj_fuzz_cases())
+def test_depthwise_projection_lds_halo_random_shapes(ops, case, prec):
+    n, h, w, c, cout, act, use_res = case
+    e = rnd((n, c, h, w), 271, 3.0).clamp(0, 6)
+    wd, sd, bd = rnd((c, 1, 3, 3), 272, 0.4), rnd((c,), 273) * 0.5 + 1.0, rnd((c,), 274)
+    wp, sp, bp = rnd((cout, c, 1, 1), 275, 1.0 / np.sqrt(c)), rnd((cout,), 276) * 0.5 + 1.0, rnd((cout,), 277)
+    dmid = torch.clamp(F.conv2d(e, wd, padding=1, groups=c) * sd.view(1, -1, 1, 1) + bd.view(1, -1, 1, 1), 0, 6)
+    ref = F.conv2d(dmid, wp) * sp.view(1, -1, 1, 1) + bp.view(1, -1, 1, 1)
+    ref = torch.clamp(ref, 0, 6) if act == 1 else (torch.sigmoid(ref) if act == 2 else ref)
+    res = rnd(tuple(ref.shape), 278) if use_res else None
+    if use_res:
+        ref = ref + res
+    got = ops.conv_gemm(nhwc(e), wp, sp, bp, act=act, res=nhwc(res) if use_res else None, prec=prec, dw=(wd, sd, bd, 1))
+    err = (nchw(got) - ref).abs().max().item()
+    assert err <= (2e-5 if prec == "f32" else TOL[prec]) * max(1.0, ref.abs().max().item()), (case, prec, err)
+
+
 def test_depthwise_projection_split_shadow(ops):
     """f16x3: the fused launch also writes the split shadow of its output (what the next GEMM stages by LDS-DMA)."""
     n, h, w, c, cout = 2, 19, 35, 96, 128
