@@ -216,6 +216,17 @@ class UAVSal(nn.Module):
             self.load_state_dict(load_reference_state_dict(pre_model_path), strict=False)
 
     # -- engines are built from the current parameter values; drop them when those change
+    def replica(self):
+        """A second handle on the SAME parameters (and packed device weights) with its own launch plans and
+        buffers.  One model's calls are ordered on its lanes; requests of independent videos issued through
+        different replicas on different host streams overlap on the GPU and fill the phases a single forward leaves
+        part of the chip idle in (the ConvTWA steps, the small backbone maps): `stream.RequestPipeline`,
+        tools/pipeline_probe.py.  Settings are copied as they are now."""
+        import copy
+        r = copy.copy(self)
+        r._engines = OrderedDict()
+        return r
+
     def _drop_engines(self):
         self._engines = OrderedDict()
         self._wshared = {}

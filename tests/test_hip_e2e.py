@@ -397,3 +397,30 @@ def test_in_place_weight_edit_rebuilds_the_plan(hip_model):
             wt.copy_(old)
     c, _ = hip_model(*args)
     assert torch.equal(a, c)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+def test_request_pipeline_equals_sequential_calls(prec):
+    """Independent requests two deep in flight on two replicas / host streams == the same requests one after another."""
+    from iip_uavsal_saliency_amd import UAVSal, synth
+    from iip_uavsal_saliency_amd.stream import RequestPipeline
+    dev = torch.device("cuda:0")
+    m = UAVSal(time_dims=4, precision=prec)
+    synth.load_synth_weights(m, 0)
+    m = m.to(dev).eval()
+    reqs = []
+    for k in range(5):
+        g = torch.Generator().manual_seed(300 + k)
+        x = torch.rand((1, 4, 3, 96, 160), generator=g).to(dev)
+        cb = [torch.rand((1, 4, 8, 12, 20), generator=g).to(dev), torch.rand((1, 4, 20, 12, 20), generator=g).to(dev)]
+        st = torch.rand((1, 256, 12, 20), generator=g).to(dev)
+        reqs.append((x, cb, st))
+    want = [m.forward_clips(x, cb, st) for x, cb, st in reqs]
+    torch.cuda.synchronize(dev)
+    pipe = RequestPipeline(m, streams=2)
+    assert pipe.models[1]._wshared is m._wshared and pipe.models[1]._engines is not m._engines
+    got = [pipe.forward_clips(x, cb, st) for x, cb, st in reqs]
+    pipe.synchronize()
+    for (wo, ws), (go, gs, _) in zip(want, got):
+        assert torch.equal(wo, go) and torch.equal(ws, gs)
