@@ -40,3 +40,26 @@ for prec in ("f32", "f16x3"):
             print("%s clips=%d streams=%d: %.1f frames/s (%.3f ms per request)" % (prec, clips, S, clips * T * n / dt, dt / n * 1e3),
                   flush=True)
             del models
+
+# the same through stream.RequestPipeline (replicas share the packed weights)
+from iip_uavsal_saliency_amd.stream import RequestPipeline
+for prec in ("f32", "f16x3"):
+    x, cb = make_clips(1, T, H, W)
+    x = x.to(dev)
+    cb = [cb[0].to(dev), cb[1].to(dev)]
+    m = UAVSal(time_dims=T, precision=prec)
+    synth.load_synth_weights(m, 0)
+    m = m.to(dev).eval()
+    for S in (1, 2):
+        pipe = RequestPipeline(m, streams=S)
+        for _ in range(4):
+            pipe.forward_clips(x, cb, None)
+        torch.cuda.synchronize(dev)
+        n = 30
+        t0 = time.perf_counter()
+        for _ in range(n):
+            pipe.forward_clips(x, cb, None)
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        pipe.synchronize()
+        print("%s RequestPipeline streams=%d: %.1f frames/s" % (prec, S, T * n / dt), flush=True)
