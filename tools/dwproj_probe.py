@@ -81,9 +81,10 @@ if __name__ == "__main__":
         run(int(sys.argv[3]) if len(sys.argv) > 3 else 8, 45, 80, 1536, 256, int(sys.argv[2]), False)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "slope":      # per-K-step cost: same launch at three depths
-        for act in ((0, 158, 134, 130) if len(sys.argv) < 3 else (0,)):
-            for hid in (384, 768, 1536, 3072):
-                run(8, 45, 80, hid, 256, act, False)
+        prec = sys.argv[3] if len(sys.argv) > 3 else "f32"
+        for act in ((0, 158, 134, 130, 132, 129, 131) if len(sys.argv) < 3 or sys.argv[2] != "product" else (0,)):
+            for hid in (768, 1536, 3072):
+                run(8, 45, 80, hid, 256, act, False, prec=prec)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "parts":      # library built with -DUAVSAL_PROBE
         for bits in (0, 2, 4, 6, 14, 30, 1, 3):
