@@ -54,6 +54,8 @@ struct ConvK {
     int* sk_flag;        // ... and its "published" flag (0 at launch, reset by the consumer)
     int* err;            // device error word (UAVSAL_ERR_*)
     int sk_spin, sk_drop;
+    int ksplit;                // dwproj_kernel: workgroups per output tile along K (1: the tile's epilogue runs in place)
+    float* kpart;              // ... and their raw partial sums [ksplit][M][Npad] (dwproj_reduce_kernel finishes them)
     const _Float16* a_sp;      // pre-split A operand (split shadow, uavsal_hip.h) or null
     _Float16* out_sp;          // optional split shadow of the output
     int ldas, ldos;            // their row strides in halves
@@ -1061,7 +1063,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 1) void dwproj_kernel(const
                                                       // instances; the first one runs the depthwise), else all four
     constexpr int E_IT = (E_REQ + 1 + NLW - 1) / NLW, B_IT = (B_REQ + NLW - 1) / NLW, NREQ = E_IT + B_IT;
     constexpr int NGRP = (H16 ? 1 : 2) * WM * WN, RPG = (NREQ + NGRP - 1) / NGRP;
-    constexpr int NTAIL = (H16 ? 2 : 1) * (WM + WN);   // fragment reads issued after a step's last MFMA
+    // fragment reads that may stay in flight across the barrier: with three A tiles everything issued after a step's
+    // last MFMA, with two only the (youngest) weight-panel reads -- the next depthwise overwrites the A tile just read
+    constexpr int NTAIL = NA == 3 ? (H16 ? 2 : 1) * (WM + WN) : WN;
     constexpr int DW_ITEMS = BM * 4 / 2 / 64;         // waves' worth of (1 x 2 strip, 4 channels) items: 4
     static_assert(WAVES_M * WM * 32 == BM, "the M tile is the 8 x 16 patch");
     static_assert(2 * B_SLOT >= 32 * BN * 4, "epilogue staging = two weight panels");
@@ -1081,7 +1085,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 1) void dwproj_kernel(const
     const int wm = wave_u / WAVES_N, wn = wave_u - wm * WAVES_N;
     const int lr = lane & 31, lh = lane >> 5;
     const int pwn = (p.W + PW - 1) / PW, phn = (p.H + PH - 1) / PH;
-    const int nst = p.Cin / KT;
+    int nst = p.Cin / KT;                              // K steps of the current tile (a share of them when K is split)
+    int ks = 0;                                        // ... and which share
     const int b_adv = p.Npad * 64;                     // F16X3: bytes between the weight panels of two K steps
 
     const uavsal_tile_walk walk = xcd_tile_walk(blockIdx.x, gridDim.x, p.nblk);
@@ -1101,6 +1106,14 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 1) void dwproj_kernel(const
         rq_lds[r] = (r < E_IT ? q <= E_REQ : q < B_REQ) ? q * 1024 : -1;
     }
     auto setup_tile = [&](int t) {
+        int s0 = 0;                                    // first K step of this workgroup's share
+        if (p.ksplit > 1) {                            // (narrow outputs: tiles_n == 1) t = tile * ksplit + share
+            const int nall = p.Cin / KT;
+            ks = t % p.ksplit;
+            t /= p.ksplit;
+            s0 = ks * nall / p.ksplit;
+            nst = (ks + 1) * nall / p.ksplit - s0;
+        }
         const int tm = t / p.tiles_n;
         n0 = (t - tm * p.tiles_n) * BN;
         img = tm / (phn * pwn);
@@ -1137,7 +1150,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 1) void dwproj_kernel(const
                 src = H16 ? reinterpret_cast<const float*>(p.w + (size_t)nn * 64) + lc * 4       // [step][Npad][64 B]
                           : reinterpret_cast<const float*>(p.w) + (size_t)nn * p.Kpad + lc * 4;
             }
-            rq_ptr[r] = reinterpret_cast<const char*>(src ? src : g_zero_row + ck);
+            rq_ptr[r] = reinterpret_cast<const char*>(src ? src : g_zero_row + ck) +
+                        (size_t)s0 * ((H16 && r >= E_IT) ? b_adv : KT * 4);
         }
     };
 #ifdef UAVSAL_PROBE      // tools/dwproj_probe.py parts: act = 128 + bits {1 no MFMAs, 2 no depthwise, 4 no DMA requests,
@@ -1291,7 +1305,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 1) void dwproj_kernel(const
     issue_all(0, 0);
     if (nst > 1) issue_all(E_SLOT, B_SLOT);
     while (true) {
-        const int cimg = img, cy0 = y0, cx0 = x0, cn0 = n0;
+        const int cimg = img, cy0 = y0, cx0 = x0, cn0 = n0, cks = ks;
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -1309,12 +1323,12 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 1) void dwproj_kernel(const
         load_frag(As, Bs, 1);
         // rotating slot offsets: e[i] / a[i] = slot of step kt + i (mod 3), b[i] = panel of step kt + i (mod 5)
         int e0 = 0, e1 = E_SLOT, e2 = 2 * E_SLOT;
-        int a0 = 0, a1 = A_SLOT, a2 = 2 * A_SLOT;
+        int a0 = 0, a1 = A_SLOT, a2 = NA == 3 ? 2 * A_SLOT : 0;
         int b0 = 0, b1 = B_SLOT, b2 = 2 * B_SLOT, b3 = 3 * B_SLOT, b4 = 4 * B_SLOT;
         int kt = 0;
         auto rotate = [&]() {
             int t = e0; e0 = e1; e1 = e2; e2 = t;
-            t = a0; a0 = a1; a1 = a2; a2 = t;
+            if (NA == 3) { t = a0; a0 = a1; a1 = a2; a2 = t; } else { t = a0; a0 = a1; a1 = t; a2 = a0; }
             t = b0; b0 = b1; b1 = b2; b2 = b3; b3 = b4; b4 = t;
             ++kt;
         };
@@ -1335,16 +1349,18 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 1) void dwproj_kernel(const
         // ---- epilogue: BN, activation, residual; 32-row blocks of the A-tile order through LDS
         {
             float* stg = reinterpret_cast<float*>(Bs + 2 * B_SLOT);
+            const bool part = p.ksplit > 1;        // K split: raw partial sums out, dwproj_reduce_kernel does the rest
             const bool vec = !(p.ldc & 3) && !(p.Cout & 3) && !((size_t)p.out & 15) &&
                              (!p.res || (!(p.ldr & 3) && !((size_t)p.res & 15)));
             float sc[WN], bi[WN];
 #pragma unroll
             for (int j = 0; j < WN; ++j) {
                 const int c = cn0 + (wn * WN + j) * 32 + lr;
-                const bool okn = p.scale != nullptr && c < p.Cout;
-                sc[j] = (okn ? p.scale[c] : 1.f) * (H16 ? F16X3_ACC_SCALE : 1.f);
+                const bool okn = p.scale != nullptr && c < p.Cout && !part;
+                sc[j] = part ? 1.f : (okn ? p.scale[c] : 1.f) * (H16 ? F16X3_ACC_SCALE : 1.f);
                 bi[j] = okn ? p.bias[c] : 0.f;
             }
+            const int act = part ? UAVSAL_ACT_NONE : p.act;
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -1356,7 +1372,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 1) void dwproj_kernel(const
                             const int r = (g & 3) + 8 * (g >> 2) + 4 * lh;
 #pragma unroll
                             for (int j = 0; j < WN; ++j)
-                                stg[r * BN + (wn * WN + j) * 32 + lr] = apply_act(fmaf(acc[i][j][g], sc[j], bi[j]), p.act);
+                                stg[r * BN + (wn * WN + j) * 32 + lr] = apply_act(fmaf(acc[i][j][g], sc[j], bi[j]), act);
                         }
                     }
                     __syncthreads();
@@ -1368,6 +1384,12 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 1) void dwproj_kernel(const
                         const int y = cy0 + 4 * ((rho >> 5) & 1) + ((rho >> 1) & 3);
                         const int x = cx0 + 8 * (rho >> 6) + 2 * ((rho & 1) + 2 * ((rho >> 4) & 1)) + ((rho >> 3) & 1);
                         const int gn = cn0 + c4 * 4;
+                        if (part) {
+                            if (row < 32 && y < p.H && x < p.W && gn < p.Npad)
+                                *reinterpret_cast<f32x4*>(p.kpart + ((size_t)cks * p.M + (size_t)cimg * p.HW + (size_t)y * p.W + x) * p.Npad + gn) =
+                                    *reinterpret_cast<const f32x4*>(stg + row * BN + c4 * 4);
+                            continue;
+                        }
                         if (row < 32 && y < p.H && x < p.W && gn < p.Cout) {
                             f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * BN + c4 * 4);
                             const long long pix = (long long)y * p.W + x;
@@ -1781,6 +1803,38 @@ int launch_h16_dma(const ConvK& k0, int taps, hipStream_t stream) {
     return uavsal_launch_status();
 }
 
+// Second launch of a K-split dwproj: sums the shares in a fixed order, then BN, activation, residual (and the split
+// shadow).  One thread per (pixel, 4 output channels).
+__global__ __launch_bounds__(256) void dwproj_reduce_kernel(const ConvK p, float acc_scale) {
+    const int groups = (p.Cout + 3) >> 2;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)p.M * groups) return;
+    const int m = (int)(idx / groups), gn = (int)(idx - (long long)m * groups) * 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < p.ksplit; ++k) v += *reinterpret_cast<const f32x4*>(p.kpart + ((size_t)k * p.M + m) * p.Npad + gn);
+    const int img = m / p.HW, pix = m - img * p.HW;
+    float* o = p.out + ((long long)img * p.o_is + pix) * p.ldc + gn;
+    const float* rs = p.res ? p.res + ((long long)img * p.r_is + pix) * p.ldr + gn : nullptr;
+    const bool vec = gn + 3 < p.Cout && !(p.ldc & 3) && !((size_t)p.out & 15) && (!p.res || (!(p.ldr & 3) && !((size_t)p.res & 15)));
+    f32x4 r;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const bool okc = gn + c < p.Cout;
+        const float sc = (p.scale && okc ? p.scale[gn + c] : 1.f) * acc_scale, bi = p.scale && okc ? p.bias[gn + c] : 0.f;
+        r[c] = apply_act(fmaf(v[c], sc, bi), p.act);
+        if (rs && okc && !vec) r[c] += rs[c];
+    }
+    if (vec) {
+        if (rs) r += *reinterpret_cast<const f32x4*>(rs);
+        *reinterpret_cast<f32x4*>(o) = r;
+        if (p.out_sp) uavsal_store_split4(p.out_sp + ((long long)img * p.o_is + pix) * p.ldos, gn, r);
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (gn + c < p.Cout) o[c] = r[c];
+    }
+}
+
 // LDS-halo depthwise -> projection (fp32 / split-fp16): which descriptors take it, and the launch
 bool dwproj_eligible(const uavsal_conv_desc* d) {
     static const bool on = [] { const char* e = getenv("UAVSAL_DWPROJ_LDS"); return !(e && e[0] == '0'); }();
@@ -1800,8 +1854,27 @@ int launch_dwproj_variant(const ConvK& k0, hipStream_t stream) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         return resident_grid(dwproj_kernel<PREC, WAVES_M, WAVES_N, WM, WN>, SMEM, NT);
     }();
+    // The narrowest outputs (Cout <= 32: the 1536 -> 1 decoder projection) are bound by the serial depthwise /
+    // request segments of a K step, not by the matrix pipe, and their 74 KB ring leaves room for two workgroups per
+    // CU: when the tiles alone would leave resident slots empty, K is split over 2-4 workgroups per tile (raw partial
+    // sums into the caller's workspace, summed in a fixed order by dwproj_reduce_kernel): 96 -> 72 us fp32, 88 -> 64
+    // f16x3 for 8 x 45 x 80 x 1536 -> 1.  The 64-wide instance gains nothing (81 vs 77 us: one workgroup per CU by
+    // registers in fp32, and 7 MB of partial sums to re-read), so it is not split.
+    k.ksplit = 1;
+    if (BN <= 32 && k.kpart) {
+        int ksp = cap / (k.nblk > 0 ? k.nblk : 1);
+        if (ksp > 4) ksp = 4;
+        while (ksp > 1 && (k.Cin / 16) / ksp < 12) --ksp;
+        if (ksp > 1 && (long long)ksp * k.M * k.Npad * 4 <= k0.ksplit /* workspace bytes */) k.ksplit = ksp;
+    }
+    k.nblk *= k.ksplit;
     const int grid = k.nblk < cap ? k.nblk : cap;
     hipLaunchKernelGGL((dwproj_kernel<PREC, WAVES_M, WAVES_N, WM, WN>), dim3(grid), dim3(NT), SMEM, stream, k);
+    if (k.ksplit > 1) {
+        const long long items = (long long)k.M * ((k.Cout + 3) / 4);
+        hipLaunchKernelGGL(dwproj_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream, k,
+                           PREC == UAVSAL_PREC_F16X3 ? F16X3_ACC_SCALE : 1.0f);
+    }
     return uavsal_launch_status();
 }
 
@@ -2002,7 +2075,7 @@ extern "C" int uavsal_conv_gemm(const uavsal_conv_desc* d, uavsal_stream_t strea
     k.act = d->act; k.epi = d->epi;
     k.contig = ((k.a_is == HW || k.dw_w) && k.o_is == HW && k.r_is == HW && k.x_is == HW) ? 1 : 0;
     k.tiles_n = 0; k.nblk = 0;
-    k.sk_part = nullptr; k.sk_flag = nullptr; k.err = nullptr;
+    k.sk_part = nullptr; k.sk_flag = nullptr; k.err = nullptr; k.ksplit = 1; k.kpart = nullptr;
     k.sk_spin = d->sk_spin_limit > 0 ? d->sk_spin_limit : (1 << 22);
     k.sk_drop = d->sk_debug_drop;
     const int tile = effective_tile(d);
@@ -2010,6 +2083,16 @@ extern "C" int uavsal_conv_gemm(const uavsal_conv_desc* d, uavsal_stream_t strea
     k.a_sp = (const _Float16*)d->a_split; k.ldas = d->ldas;
     k.out_sp = (_Float16*)d->out_split; k.ldos = d->ldos;
     if (split_eligible(d, tile)) return launch_h16(k, d->taps, tile, s);
+    if (dwproj_eligible(d)) {
+        // K-split workspace: the partial-tile area of the caller's stream-K workspace (launches on one lane are ordered)
+        k.kpart = nullptr;
+        k.ksplit = 0;
+        if (d->sk_ws && uavsal_aligned16(d->sk_ws) && d->sk_ws_bytes > 65536) {
+            k.kpart = (float*)((char*)d->sk_ws + 65536);
+            const long long avail = d->sk_ws_bytes - 65536;
+            k.ksplit = avail > 0x7fffffffLL ? 0x7fffffff : (int)avail;          // bytes available, read by the launcher
+        }
+    }
     if (dwproj_eligible(d))
         return d->prec == UAVSAL_PREC_F32 ? launch_dwproj<UAVSAL_PREC_F32>(k, s) : launch_dwproj<UAVSAL_PREC_F16X3>(k, s);
     if (!d->a) return UAVSAL_EINVAL;             // pre-split operands given but the shape is not eligible

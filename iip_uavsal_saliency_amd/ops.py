@@ -112,7 +112,7 @@ def conv_gemm(x, weight, scale=None, bias=None, act=L.ACT_NONE, res=None, out=No
         d.res, d.ldr, d.r_img_stride = rp, ldr, h * w
     d.n_img, d.H, d.W, d.Cin, d.Cout, d.taps = n, h, w, cin, cout, taps
     d.prec, d.act, d.epi, d.tile = L.PREC[prec], act, L.EPI_AFFINE, tile
-    if stream_k:
+    if stream_k or dw is not None:      # (the depthwise -> projection launch splits K of narrow outputs through it)
         ws = torch.zeros(int(lib.uavsal_streamk_workspace_bytes()), dtype=torch.uint8, device=x.device)
         keep.append(ws)
         d.sk_ws, d.sk_ws_bytes = ws.data_ptr(), ws.numel()

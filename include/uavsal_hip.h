@@ -128,7 +128,10 @@ typedef struct uavsal_conv_desc {
      * F32 / F16X3, dw_stride 1, Cin % 16 == 0 (<= 4096) run the LDS-halo kernel (a workgroup stages the 10 x 18
      * halo of an 8 x 16 pixel patch per 16 channels, computes the depthwise in LDS and feeds the MFMA loop:
      * uavsal_conv_dwproj tells; its F16X3 form takes the weights as [Cin/16][Npad][hi 16 | lo 16] fp16 lines of
-     * 64 w, packing.py 'f16x3j'); everything else the register-staged loader of round 1 (correct, latency-bound). */
+     * 64 w, packing.py 'f16x3j'); everything else the register-staged loader of round 1 (correct, latency-bound).
+     * With `sk_ws` set, narrow outputs (Cout <= 32) whose tiles would leave workgroup slots empty split K over 2-4
+     * workgroups per tile: raw partial sums go to the partial-tile area of `sk_ws` and a second small launch sums them
+     * in a fixed order and applies BN / activation / residual (deterministic; no atomics). */
     const float* dw_w9c; const float* dw_scale; const float* dw_bias;
     int32_t dw_stride, dw_Hin, dw_Win;
     /* Optional stream-K workspace (fp32, 128x128 and 64x64 tiles; 64 KB of flags, then partial tiles): `uavsal_streamk_workspace_bytes()` bytes of device

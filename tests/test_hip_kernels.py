@@ -276,6 +276,9 @@ DWPROJ_CASES = [
     (2, 9, 17, 48, 128, 0, True, True), (1, 8, 16, 64, 64, 0, False, False), (2, 1, 37, 32, 40, 1, False, True),
     (1, 23, 1, 16, 24, 0, False, False), (17, 7, 5, 80, 32, 2, False, False), (1, 90, 160, 64, 256, 0, False, False),
     (40, 17, 33, 16, 300, 0, True, False),
+    # narrow outputs with few tiles and a long K walk: K is split over 2-4 workgroups per tile + the reduce launch
+    (1, 16, 32, 768, 1, 2, False, False), (2, 9, 20, 384, 40, 1, True, True), (1, 8, 16, 1024, 64, 0, True, False),
+    (3, 20, 20, 400, 33, 0, False, False),
 ]
 
 

@@ -59,8 +59,8 @@ def run(n_img, h, w, hid, cout, act=0, use_res=False, stream_k=True, prec="f32")
         if fused:
             d.dw_w9c, d.dw_scale, d.dw_bias = w9.data_ptr(), sd.data_ptr(), bd.data_ptr()
             d.dw_stride, d.dw_Hin, d.dw_Win = 1, h, w
-        elif stream_k:
-            d.sk_ws, d.sk_ws_bytes = ws.data_ptr(), ws.numel()
+        if stream_k and (not fused or os.environ.get("DWPROJ_KSPLIT", "1") != "0"):
+            d.sk_ws, d.sk_ws_bytes = ws.data_ptr(), ws.numel()     # stream-K / K-split workspace
         return d
     dp = conv_desc(dmid, out_a, False)
     df = conv_desc(e, out_b, True)
