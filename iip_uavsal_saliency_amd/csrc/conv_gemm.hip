@@ -360,7 +360,13 @@ void conv_gemm_kernel(const ConvK p) {
     // the conversion VALU work and the barrier-phased MFMA / VALU alternation, not by load latency:
     // D = 1, 2, 3 are within 3% on the 4-wave tiles (1 is best and cheapest in registers); only the
     // 8-wave 128 x 256 tile, alone on its CU, gains from D = 2 (up to 9% on the 64-frame expands).
-    constexpr int D = (!FUSE && WAVES_M * WAVES_N == 8 && WM * WN <= 4) ? UAVSAL_GEMM_PREFETCH : 1;
+    // ... and the 64 x 64 3x3 tile of the ConvTWA steps (228 tiles: one workgroup per CU, nothing else covers a
+    // load): D = 2 measured 50 vs 52 us per step and +1.1 % end to end in f16x3 at one clip (3: slower)
+#ifndef UAVSAL_GEMM_PREFETCH_SMALL
+#define UAVSAL_GEMM_PREFETCH_SMALL 2
+#endif
+    constexpr int D = (!FUSE && WAVES_M * WAVES_N == 8 && WM * WN <= 4) ? UAVSAL_GEMM_PREFETCH
+                      : ((!FUSE && WM * WN == 1 && TAPS == 9) ? UAVSAL_GEMM_PREFETCH_SMALL : 1);
     f32x4 a_reg[D][A_IT][NLD];
     u32x4 b_reg[D][B_IT][NPAN];
 
