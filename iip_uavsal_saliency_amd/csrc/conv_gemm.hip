@@ -54,8 +54,10 @@ struct ConvK {
     int* sk_flag;        // ... and its "published" flag (0 at launch, reset by the consumer)
     int* err;            // device error word (UAVSAL_ERR_*)
     int sk_spin, sk_drop;
-    int ksplit;                // dwproj_kernel: workgroups per output tile along K (1: the tile's epilogue runs in place)
-    float* kpart;              // ... and their raw partial sums [ksplit][M][Npad] (dwproj_reduce_kernel finishes them)
+    int ksplit;                // K split (dwproj_kernel, the 64x64 3x3 register-staged tile): workgroups per output tile
+                               // along K; 1: the tile's epilogue runs in place
+    float* kpart;              // ... their raw partial sums [ksplit][M][Npad] (splitk_reduce_kernel finishes them)
+    long long kpart_bytes;     // ... and the room there is for them
     const _Float16* a_sp;      // pre-split A operand (split shadow, uavsal_hip.h) or null
     _Float16* out_sp;          // optional split shadow of the output
     int ldas, ldos;            // their row strides in halves
@@ -292,6 +294,13 @@ void conv_gemm_kernel(const ConvK p) {
     const int tile_end = walk.end, tile_step = walk.stride;
     if (tile >= tile_end) return;
     int m0 = 0, n0 = 0;
+    // K split (host: launch_variant): only the 64 x 64 3x3 tile carries it -- the ConvTWA step is 228 tiles with 72 K
+    // steps each, one workgroup per CU and a serial load -> convert -> multiply chain per step; `tile` then counts
+    // (output tile, share) pairs and a share's raw sums go to p.kpart
+    constexpr bool CAN_SPLIT = TAPS == 9 && WM * WN == 1 && !FUSE;
+    const int KS = CAN_SPLIT ? p.ksplit : 1;
+    const int kshare = p.ktiles / KS;              // K steps per share (host: divisible, a multiple of 9 steps)
+    int l_base = 0;                                // first K step of the share the loader is in
 
     // ---- per-thread staging coordinates ------------------------------------------------
     const int stid = tid;
@@ -304,6 +313,11 @@ void conv_gemm_kernel(const ConvK p) {
     bool a_ok[A_IT];
     unsigned b_off[B_IT];
     auto setup_tile = [&](int t) {
+        if (CAN_SPLIT && KS > 1) {
+            const int tt = t / KS;
+            l_base = (t - tt * KS) * kshare;
+            t = tt;
+        }
         const int tile_m = t / p.tiles_n;
         const int tile_n = t - tile_m * p.tiles_n;
         m0 = tile_m * BM;
@@ -570,14 +584,15 @@ void conv_gemm_kernel(const ConvK p) {
     // nothing), so a tile always starts in register set 0.  EVERY step issues the same number of
     // loads, unconditionally: with a load behind a branch -- even a uniform one -- the compiler's
     // waitcnt pass merges the two paths and waits for vmcnt(0), which is prefetch distance 1 again.
-    const int S = (p.ktiles + D - 1) / D * D;
+    const int S = (kshare + D - 1) / D * D;
     int l_tile = tile, l_s = 0;                  // loader position
     int lt_tap = 0, lt_ci = 0;                   // its running K position (advanced in order)
     int l_kt = 0, l_ci0 = 0, l_tapv = 0;         // what the last real step requested
     setup_tile(l_tile);
+    if (CAN_SPLIT) lt_ci = (l_base / 9) * KT;    // a share starts on a channel block (tap 0)
     auto loader_step = [&](int set) {
-        if (l_s < p.ktiles) {
-            l_kt = l_s; l_ci0 = lt_ci; l_tapv = lt_tap;
+        if (l_s < kshare) {
+            l_kt = l_base + l_s; l_ci0 = lt_ci; l_tapv = lt_tap;
             // 3x3: K runs channel-block-major, tap-minor -- the nine taps of one 64/128-byte channel
             // chunk are nine consecutive K steps, so every fetched line sees all its uses while it
             // is still in L2 (tap-major re-fetched the activations ~6x: PMC FETCH_SIZE)
@@ -586,11 +601,12 @@ void conv_gemm_kernel(const ConvK p) {
         }
         load_tile(l_kt, l_ci0, l_tapv, set);
         if (++l_s == S) {
-            l_s = 0; lt_ci = 0; lt_tap = 0;
+            l_s = 0; lt_tap = 0;
             if (l_tile + tile_step < tile_end) {  // past the last tile: keep re-requesting it (harmless)
                 l_tile += tile_step;
                 setup_tile(l_tile);
             }
+            lt_ci = CAN_SPLIT ? (l_base / 9) * KT : 0;
         }
     };
 
@@ -598,8 +614,10 @@ void conv_gemm_kernel(const ConvK p) {
 #pragma unroll
     for (int d = 0; d < D; ++d) loader_step(d);
     while (true) {
-        const int tile_m = tile / p.tiles_n;
-        const int m0c = tile_m * BM, n0c = (tile - tile_m * p.tiles_n) * BN;   // tile being computed
+        const int otile = (CAN_SPLIT && KS > 1) ? tile / KS : tile;
+        const int cks = tile - otile * KS;                                      // (share being computed)
+        const int tile_m = otile / p.tiles_n;
+        const int m0c = tile_m * BM, n0c = (otile - tile_m * p.tiles_n) * BN;  // tile being computed
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -617,15 +635,27 @@ void conv_gemm_kernel(const ConvK p) {
                 // keep the order request -> multiply -> convert: hoisting the conversion of step
                 // st+1 above these requests would drain vmcnt first
                 if (D > 1) __builtin_amdgcn_sched_barrier(0);
-                if (st < p.ktiles) compute(st & 1);
+                if (st < kshare) compute(st & 1);
                 if (D > 1) __builtin_amdgcn_sched_barrier(0);
-                if (st + 1 < p.ktiles) store_tile((u + 1) % D, (st + 1) & 1);
+                if (st + 1 < kshare) store_tile((u + 1) % D, (st + 1) & 1);
                 __syncthreads();
             }
         }
 
         // ---- epilogue ------------------------------------------------------------------
-        UAVSAL_GEMM_EPILOGUE((PREC == UAVSAL_PREC_F16X3 ? F16X3_ACC_SCALE : 1.0f), smem, (PREC == UAVSAL_PREC_F16X3))
+        if (CAN_SPLIT && KS > 1) {
+            // a share: raw sums out (32 consecutive floats per lane row), splitk_reduce_kernel does the rest
+            if constexpr (CAN_SPLIT) {
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const int m = m0c + wm * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
+                    const int n = n0c + wn * 32 + lr;
+                    if (m < p.M && n < p.Npad) p.kpart[((size_t)cks * p.M + m) * p.Npad + n] = acc[0][0][g];
+                }
+            }
+        } else {
+            UAVSAL_GEMM_EPILOGUE((PREC == UAVSAL_PREC_F16X3 ? F16X3_ACC_SCALE : 1.0f), smem, (PREC == UAVSAL_PREC_F16X3))
+        }
         tile += tile_step;
         if (tile >= tile_end) break;
     }
@@ -1647,6 +1677,54 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_gemm_h16_dma_k
     }
 }
 
+// Second launch of a K-split GEMM (dwproj_kernel's narrow instance, the 64x64 3x3 tile of the ConvTWA step): sums the
+// shares in a fixed order, then the epilogue -- BN, activation, residual, or the ConvTWA update (model_convlstm.py:
+// 276-292: gate = sigmoid(sum + W_x x_t), h_t = gate x_t + (1 - gate) h_{t-1}) -- and the split shadow.
+// One thread per (row, 4 output channels).
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvK p, float acc_scale) {
+    const int groups = (p.Cout + 3) >> 2;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)p.M * groups) return;
+    const int m = (int)(idx / groups), gn = (int)(idx - (long long)m * groups) * 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < p.ksplit; ++k) v += *reinterpret_cast<const f32x4*>(p.kpart + ((size_t)k * p.M + m) * p.Npad + gn);
+    const int img = m / p.HW, pix = m - img * p.HW;
+    float* o = p.out + ((long long)img * p.o_is + pix) * p.ldc + gn;
+    const float* rs = p.res ? p.res + ((long long)img * p.r_is + pix) * p.ldr + gn : nullptr;
+    const bool twa = p.epi == UAVSAL_EPI_TWA;
+    const float* ax = twa ? p.aux + ((long long)img * p.x_is + pix) * p.ldx + gn : nullptr;
+    const float* hp = twa ? p.a + ((long long)img * p.a_is + pix) * p.lda + gn : nullptr;
+    const bool vec = gn + 3 < p.Cout && !(p.ldc & 3) && !((size_t)p.out & 15) && (!p.res || (!(p.ldr & 3) && !((size_t)p.res & 15)));
+    f32x4 r;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const bool okc = gn + c < p.Cout;
+        if (twa) {
+            const float z = v[c] * acc_scale + (okc ? ax[c] : 0.f);
+            const float gate = 1.f / (1.f + expf(-z));
+            r[c] = okc ? gate * rs[c] + (1.f - gate) * hp[c] : 0.f;
+        } else {
+            const float sc = (p.scale && okc ? p.scale[gn + c] : 1.f) * acc_scale, bi = p.scale && okc ? p.bias[gn + c] : 0.f;
+            r[c] = apply_act(fmaf(v[c], sc, bi), p.act);
+            if (rs && okc) r[c] += rs[c];
+        }
+    }
+    if (vec) {
+        *reinterpret_cast<f32x4*>(o) = r;
+        if (p.out_sp) uavsal_store_split4(p.out_sp + ((long long)img * p.o_is + pix) * p.ldos, gn, r);
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (gn + c < p.Cout) o[c] = r[c];
+    }
+}
+
+int launch_splitk_reduce(const ConvK& k, float acc_scale, hipStream_t stream) {
+    const long long items = (long long)k.M * ((k.Cout + 3) / 4);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream, k, acc_scale);
+    return uavsal_launch_status();
+}
+
 // resident workgroups per CU for one kernel instantiation (cached; queried once, outside any capture)
 template <typename K>
 int resident_grid(K kernel, int smem, int threads = 256) {
@@ -1681,8 +1759,23 @@ int launch_variant(const ConvK& k0, int taps, hipStream_t stream) {
         hipLaunchKernelGGL((conv_gemm_kernel<PREC, WAVES_M, WAVES_N, WM, WN, 1>), dim3(grid), dim3(NT), SMEM, stream, k);
     } else {
         static const int cap = resident_grid(conv_gemm_kernel<PREC, WAVES_M, WAVES_N, WM, WN, 9>, SMEM, NT);
+        // 64 x 64 tile with fewer tiles than CUs-worth of slots and a long K walk (the ConvTWA step: 228 tiles x 72 K
+        // steps): split K over 2 or 4 workgroups per tile; the shares' sums meet in splitk_reduce_kernel
+        if (WM * WN == 1 && k.kpart && (k.epi == UAVSAL_EPI_TWA || k.epi == UAVSAL_EPI_AFFINE) &&
+            (PREC == UAVSAL_PREC_F16X3 || PREC == UAVSAL_PREC_BF16X3)) {
+            static const bool on = [] { const char* e = getenv("UAVSAL_SPLITK_3X3"); return !(e && e[0] == '0'); }();
+            int ksp = on ? cap / (k.nblk > 0 ? k.nblk : 1) : 1;
+            ksp = ksp >= 4 ? 4 : (ksp >= 2 ? 2 : 1);
+            while (ksp > 1 && (k.ktiles % (9 * ksp) || k.ktiles / ksp < 18)) ksp >>= 1;
+            if (ksp > 1 && (long long)ksp * k.M * k.Npad * 4 <= k.kpart_bytes && !(k.Cout & 3) && !(k.ldc & 3) &&
+                (k.epi != UAVSAL_EPI_TWA || (!(k.ldx & 3) && !(k.lda & 3) && !(k.ldr & 3)))) {
+                k.ksplit = ksp;
+                k.nblk *= ksp;
+            }
+        }
         const int grid = k.nblk < cap ? k.nblk : cap;
         hipLaunchKernelGGL((conv_gemm_kernel<PREC, WAVES_M, WAVES_N, WM, WN, 9>), dim3(grid), dim3(NT), SMEM, stream, k);
+        if (k.ksplit > 1) return launch_splitk_reduce(k, PREC == UAVSAL_PREC_F16X3 ? F16X3_ACC_SCALE : 1.0f, stream);
     }
     return uavsal_launch_status();
 }
@@ -1809,38 +1902,6 @@ int launch_h16_dma(const ConvK& k0, int taps, hipStream_t stream) {
     return uavsal_launch_status();
 }
 
-// Second launch of a K-split dwproj: sums the shares in a fixed order, then BN, activation, residual (and the split
-// shadow).  One thread per (pixel, 4 output channels).
-__global__ __launch_bounds__(256) void dwproj_reduce_kernel(const ConvK p, float acc_scale) {
-    const int groups = (p.Cout + 3) >> 2;
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long long)p.M * groups) return;
-    const int m = (int)(idx / groups), gn = (int)(idx - (long long)m * groups) * 4;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < p.ksplit; ++k) v += *reinterpret_cast<const f32x4*>(p.kpart + ((size_t)k * p.M + m) * p.Npad + gn);
-    const int img = m / p.HW, pix = m - img * p.HW;
-    float* o = p.out + ((long long)img * p.o_is + pix) * p.ldc + gn;
-    const float* rs = p.res ? p.res + ((long long)img * p.r_is + pix) * p.ldr + gn : nullptr;
-    const bool vec = gn + 3 < p.Cout && !(p.ldc & 3) && !((size_t)p.out & 15) && (!p.res || (!(p.ldr & 3) && !((size_t)p.res & 15)));
-    f32x4 r;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const bool okc = gn + c < p.Cout;
-        const float sc = (p.scale && okc ? p.scale[gn + c] : 1.f) * acc_scale, bi = p.scale && okc ? p.bias[gn + c] : 0.f;
-        r[c] = apply_act(fmaf(v[c], sc, bi), p.act);
-        if (rs && okc && !vec) r[c] += rs[c];
-    }
-    if (vec) {
-        if (rs) r += *reinterpret_cast<const f32x4*>(rs);
-        *reinterpret_cast<f32x4*>(o) = r;
-        if (p.out_sp) uavsal_store_split4(p.out_sp + ((long long)img * p.o_is + pix) * p.ldos, gn, r);
-    } else {
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-            if (gn + c < p.Cout) o[c] = r[c];
-    }
-}
-
 // LDS-halo depthwise -> projection (fp32 / split-fp16): which descriptors take it, and the launch
 bool dwproj_eligible(const uavsal_conv_desc* d) {
     static const bool on = [] { const char* e = getenv("UAVSAL_DWPROJ_LDS"); return !(e && e[0] == '0'); }();
@@ -1871,16 +1932,12 @@ int launch_dwproj_variant(const ConvK& k0, hipStream_t stream) {
         int ksp = cap / (k.nblk > 0 ? k.nblk : 1);
         if (ksp > 4) ksp = 4;
         while (ksp > 1 && (k.Cin / 16) / ksp < 12) --ksp;
-        if (ksp > 1 && (long long)ksp * k.M * k.Npad * 4 <= k0.ksplit /* workspace bytes */) k.ksplit = ksp;
+        if (ksp > 1 && (long long)ksp * k.M * k.Npad * 4 <= k.kpart_bytes) k.ksplit = ksp;
     }
     k.nblk *= k.ksplit;
     const int grid = k.nblk < cap ? k.nblk : cap;
     hipLaunchKernelGGL((dwproj_kernel<PREC, WAVES_M, WAVES_N, WM, WN>), dim3(grid), dim3(NT), SMEM, stream, k);
-    if (k.ksplit > 1) {
-        const long long items = (long long)k.M * ((k.Cout + 3) / 4);
-        hipLaunchKernelGGL(dwproj_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream, k,
-                           PREC == UAVSAL_PREC_F16X3 ? F16X3_ACC_SCALE : 1.0f);
-    }
+    if (k.ksplit > 1) return launch_splitk_reduce(k, PREC == UAVSAL_PREC_F16X3 ? F16X3_ACC_SCALE : 1.0f, stream);
     return uavsal_launch_status();
 }
 
@@ -2081,7 +2138,7 @@ extern "C" int uavsal_conv_gemm(const uavsal_conv_desc* d, uavsal_stream_t strea
     k.act = d->act; k.epi = d->epi;
     k.contig = ((k.a_is == HW || k.dw_w) && k.o_is == HW && k.r_is == HW && k.x_is == HW) ? 1 : 0;
     k.tiles_n = 0; k.nblk = 0;
-    k.sk_part = nullptr; k.sk_flag = nullptr; k.err = nullptr; k.ksplit = 1; k.kpart = nullptr;
+    k.sk_part = nullptr; k.sk_flag = nullptr; k.err = nullptr; k.ksplit = 1; k.kpart = nullptr; k.kpart_bytes = 0;
     k.sk_spin = d->sk_spin_limit > 0 ? d->sk_spin_limit : (1 << 22);
     k.sk_drop = d->sk_debug_drop;
     const int tile = effective_tile(d);
@@ -2089,15 +2146,10 @@ extern "C" int uavsal_conv_gemm(const uavsal_conv_desc* d, uavsal_stream_t strea
     k.a_sp = (const _Float16*)d->a_split; k.ldas = d->ldas;
     k.out_sp = (_Float16*)d->out_split; k.ldos = d->ldos;
     if (split_eligible(d, tile)) return launch_h16(k, d->taps, tile, s);
-    if (dwproj_eligible(d)) {
-        // K-split workspace: the partial-tile area of the caller's stream-K workspace (launches on one lane are ordered)
-        k.kpart = nullptr;
-        k.ksplit = 0;
-        if (d->sk_ws && uavsal_aligned16(d->sk_ws) && d->sk_ws_bytes > 65536) {
-            k.kpart = (float*)((char*)d->sk_ws + 65536);
-            const long long avail = d->sk_ws_bytes - 65536;
-            k.ksplit = avail > 0x7fffffffLL ? 0x7fffffff : (int)avail;          // bytes available, read by the launcher
-        }
+    // K-split workspace: the partial-tile area of the caller's stream-K workspace (launches on one lane are ordered)
+    if (d->sk_ws && uavsal_aligned16(d->sk_ws) && d->sk_ws_bytes > 65536) {
+        k.kpart = (float*)((char*)d->sk_ws + 65536);
+        k.kpart_bytes = d->sk_ws_bytes - 65536;
     }
     if (dwproj_eligible(d))
         return d->prec == UAVSAL_PREC_F32 ? launch_dwproj<UAVSAL_PREC_F32>(k, s) : launch_dwproj<UAVSAL_PREC_F16X3>(k, s);

@@ -217,6 +217,37 @@ def test_twa_step_stream_k(ops):
     assert (nchw(split) - ref).abs().max().item() <= TOL["f32"] * 4.0
 
 
+@pytest.mark.parametrize("prec", ["f16x3", "bf16x3"])
+@pytest.mark.parametrize("shape", [(1, 45, 80), (2, 12, 20), (1, 23, 40)])
+def test_twa_step_split_k(ops, prec, shape):
+    """Split-16-bit ConvTWA step with the workspace: few 64 x 64 tiles and 72 K steps -> K is split over 2-4
+    workgroups per tile, the shares meet in the reduce launch (which also does the ConvTWA update)."""
+    n, h, w = shape
+    c = 256
+    x = rnd((n, c, h, w), 47, 2.0)
+    hp = rnd((n, c, h, w), 48, 2.0)
+    wt = rnd((c, 2 * c, 3, 3), 49, 1.0 / np.sqrt(9 * 2 * c))
+    gate = torch.sigmoid(F.conv2d(torch.cat([x, hp], 1), wt, padding=1))
+    ref = gate * x + (1 - gate) * hp
+    pre = ops.conv_gemm(nhwc(x), wt[:, :c].contiguous(), None, None, prec=prec)
+    whole = ops.twa_step(nhwc(x), nhwc(hp), pre, wt[:, c:].contiguous(), prec=prec)
+    split = ops.twa_step(nhwc(x), nhwc(hp), pre, wt[:, c:].contiguous(), prec=prec, stream_k=True)
+    assert (split - whole).abs().max().item() <= TOL[prec] * 4.0
+    assert (nchw(split) - ref).abs().max().item() <= TOL[prec] * 4.0
+
+
+def test_conv3x3_small_map_split_k(ops):
+    """A plain 3x3 conv (BN + ReLU6 + residual) on a small map in f16x3 with the workspace: same split path, affine epilogue."""
+    x = rnd((2, 64, 23, 40), 51, 2.0)
+    wt = rnd((64, 64, 3, 3), 52, 1.0 / np.sqrt(9 * 64))
+    sc, bi = rnd((64,), 53) * 0.5 + 1.0, rnd((64,), 54)
+    res = rnd((2, 64, 23, 40), 55)
+    ref = torch.clamp(F.conv2d(x, wt, padding=1) * sc.view(1, -1, 1, 1) + bi.view(1, -1, 1, 1), 0, 6) + res
+    from iip_uavsal_saliency_amd import _lib as L
+    got = ops.conv_gemm(nhwc(x), wt, sc, bi, act=L.ACT_RELU6, res=nhwc(res), prec="f16x3", tile=4, stream_k=True)
+    assert (nchw(got) - ref).abs().max().item() <= TOL["f16x3"] * 4.0
+
+
 @pytest.mark.parametrize("prec", ["f32", "f16x3"])
 def test_convlstm_step_vs_reference_golden(ops, prec, golden_dir):
     """ConvLSTMCell.forward: the golden was produced by the reference's own model_convlstm.py."""
