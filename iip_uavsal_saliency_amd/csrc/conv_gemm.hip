@@ -294,10 +294,11 @@ void conv_gemm_kernel(const ConvK p) {
     const int tile_end = walk.end, tile_step = walk.stride;
     if (tile >= tile_end) return;
     int m0 = 0, n0 = 0;
-    // K split (host: launch_variant): only the 64 x 64 3x3 tile carries it -- the ConvTWA step is 228 tiles with 72 K
-    // steps each, one workgroup per CU and a serial load -> convert -> multiply chain per step; `tile` then counts
-    // (output tile, share) pairs and a share's raw sums go to p.kpart
-    constexpr bool CAN_SPLIT = TAPS == 9 && WM * WN == 1 && !FUSE;
+    // K split (host: launch_variant): only the 64 x 64 tile carries it -- the ConvTWA step is 228 tiles with 72 K
+    // steps each (the 12x20 ASPP projections: 120 tiles x 60 steps), one workgroup per CU and a serial load ->
+    // convert -> multiply chain per step; `tile` then counts (output tile, share) pairs and a share's raw sums go to
+    // p.kpart
+    constexpr bool CAN_SPLIT = WM * WN == 1 && !FUSE;
     const int KS = CAN_SPLIT ? p.ksplit : 1;
     const int kshare = p.ktiles / KS;              // K steps per share (host: divisible, a multiple of 9 steps)
     int l_base = 0;                                // first K step of the share the loader is in
@@ -589,7 +590,7 @@ void conv_gemm_kernel(const ConvK p) {
     int lt_tap = 0, lt_ci = 0;                   // its running K position (advanced in order)
     int l_kt = 0, l_ci0 = 0, l_tapv = 0;         // what the last real step requested
     setup_tile(l_tile);
-    if (CAN_SPLIT) lt_ci = (l_base / 9) * KT;    // a share starts on a channel block (tap 0)
+    if (CAN_SPLIT) lt_ci = (TAPS == 9 ? l_base / 9 : l_base) * KT;    // (3x3: a share starts on a channel block, tap 0)
     auto loader_step = [&](int set) {
         if (l_s < kshare) {
             l_kt = l_base + l_s; l_ci0 = lt_ci; l_tapv = lt_tap;
@@ -606,7 +607,7 @@ void conv_gemm_kernel(const ConvK p) {
                 l_tile += tile_step;
                 setup_tile(l_tile);
             }
-            lt_ci = CAN_SPLIT ? (l_base / 9) * KT : 0;
+            lt_ci = CAN_SPLIT ? (TAPS == 9 ? l_base / 9 : l_base) * KT : 0;
         }
     };
 
@@ -1755,8 +1756,20 @@ int launch_variant(const ConvK& k0, int taps, hipStream_t stream) {
         }
     } else if (taps == 1) {
         static const int cap = resident_grid(conv_gemm_kernel<PREC, WAVES_M, WAVES_N, WM, WN, 1>, SMEM, NT);
+        // (same K split as the 3x3 tile below: few 64 x 64 tiles, long K -- the 1920 -> 256 ASPP projections at 12x20)
+        if (WM * WN == 1 && k.kpart && k.epi == UAVSAL_EPI_AFFINE && (PREC == UAVSAL_PREC_F16X3 || PREC == UAVSAL_PREC_BF16X3)) {
+            static const bool on = [] { const char* e = getenv("UAVSAL_SPLITK_1X1"); return !(e && e[0] == '0'); }();
+            int ksp = on ? cap / (k.nblk > 0 ? k.nblk : 1) : 1;
+            ksp = ksp >= 4 ? 4 : (ksp >= 2 ? 2 : 1);
+            while (ksp > 1 && (k.ktiles % ksp || k.ktiles / ksp < 12)) ksp >>= 1;
+            if (ksp > 1 && (long long)ksp * k.M * k.Npad * 4 <= k.kpart_bytes && !(k.Cout & 3) && !(k.ldc & 3)) {
+                k.ksplit = ksp;
+                k.nblk *= ksp;
+            }
+        }
         const int grid = k.nblk < cap ? k.nblk : cap;
         hipLaunchKernelGGL((conv_gemm_kernel<PREC, WAVES_M, WAVES_N, WM, WN, 1>), dim3(grid), dim3(NT), SMEM, stream, k);
+        if (k.ksplit > 1) return launch_splitk_reduce(k, PREC == UAVSAL_PREC_F16X3 ? F16X3_ACC_SCALE : 1.0f, stream);
     } else {
         static const int cap = resident_grid(conv_gemm_kernel<PREC, WAVES_M, WAVES_N, WM, WN, 9>, SMEM, NT);
         // 64 x 64 tile with fewer tiles than CUs-worth of slots and a long K walk (the ConvTWA step: 228 tiles x 72 K

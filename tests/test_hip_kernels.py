@@ -236,6 +236,20 @@ def test_twa_step_split_k(ops, prec, shape):
     assert (nchw(split) - ref).abs().max().item() <= TOL[prec] * 4.0
 
 
+@pytest.mark.parametrize("prec", ["f16x3", "bf16x3"])
+def test_conv1x1_small_map_split_k(ops, prec):
+    """1x1 projection with a long K on a small map (ASPP: 1920 -> 256 at 12x20) with the workspace: K split + reduce launch."""
+    x = rnd((2, 1920, 12, 20), 56, 2.0)
+    wt = rnd((256, 1920, 1, 1), 57, 1.0 / np.sqrt(1920))
+    sc, bi = rnd((256,), 58) * 0.5 + 1.0, rnd((256,), 59)
+    res = rnd((2, 256, 12, 20), 60)
+    ref = F.conv2d(x, wt) * sc.view(1, -1, 1, 1) + bi.view(1, -1, 1, 1) + res
+    got = ops.conv_gemm(nhwc(x), wt, sc, bi, res=nhwc(res), prec=prec, tile=4, stream_k=True)
+    whole = ops.conv_gemm(nhwc(x), wt, sc, bi, res=nhwc(res), prec=prec, tile=4)
+    assert (got - whole).abs().max().item() <= TOL[prec] * 4.0
+    assert (nchw(got) - ref).abs().max().item() <= TOL[prec] * 4.0
+
+
 def test_conv3x3_small_map_split_k(ops):
     """A plain 3x3 conv (BN + ReLU6 + residual) on a small map in f16x3 with the workspace: same split path, affine epilogue."""
     x = rnd((2, 64, 23, 40), 51, 2.0)
