@@ -250,6 +250,19 @@ def test_conv1x1_small_map_split_k(ops, prec):
     assert (nchw(got) - ref).abs().max().item() <= TOL[prec] * 4.0
 
 
+@pytest.mark.parametrize("case", [(2, 13, 17, 1024, 96), (1, 7, 9, 768, 36), (3, 5, 5, 2048, 200)])
+def test_conv1x1_split_k_ragged(ops, case):
+    """K split with row counts that are no tile multiple and output widths that leave a partial last 64-wide tile."""
+    n, h, w, cin, cout = case
+    x = rnd((n, cin, h, w), 61, 2.0)
+    wt = rnd((cout, cin, 1, 1), 62, 1.0 / np.sqrt(cin))
+    sc, bi = rnd((cout,), 63) * 0.5 + 1.0, rnd((cout,), 64)
+    ref = torch.clamp(F.conv2d(x, wt) * sc.view(1, -1, 1, 1) + bi.view(1, -1, 1, 1), 0, 6)
+    from iip_uavsal_saliency_amd import _lib as L
+    got = ops.conv_gemm(nhwc(x), wt, sc, bi, act=L.ACT_RELU6, prec="f16x3", tile=4, stream_k=True)
+    assert (nchw(got) - ref).abs().max().item() <= TOL["f16x3"] * 4.0
+
+
 def test_conv3x3_small_map_split_k(ops):
     """A plain 3x3 conv (BN + ReLU6 + residual) on a small map in f16x3 with the workspace: same split path, affine epilogue."""
     x = rnd((2, 64, 23, 40), 51, 2.0)
