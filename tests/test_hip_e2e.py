@@ -277,6 +277,22 @@ def test_graph_replay_matches_launch_loop(hip_model):
     assert torch.equal(a, b) and torch.equal(sa, sb) and torch.equal(a, b2)
 
 
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+def test_fused_depthwise_projection_everywhere_matches_three_launches(hip_model, prec):
+    """`fuse_dw=True` puts EVERY dilation-1 block's depthwise inside its projection launch (the default only does so
+    for the big blocks: at this size none), `False` none: the maps must agree to rounding."""
+    x, cb = make_inputs(4, 96, 160)
+    try:
+        hip_model.fuse_dw = False
+        a, sa = _run_hip(hip_model, 4, prec, x, cb)
+        hip_model.fuse_dw = True
+        b, sb = _run_hip(hip_model, 4, prec, x, cb)
+    finally:
+        hip_model.fuse_dw = None
+    tol = 2e-4 if prec == "f32" else 3e-4     # (fp32 summation orders differ in ~20 layers: ~5e-5 on the map)
+    assert (a - b).abs().max().item() <= tol and (sa - sb).abs().max().item() <= tol * 5
+
+
 def test_error_behaviour(hip_model):
     x, cb = make_inputs(4, 96, 160)
     hip_model.time_dims = 4
