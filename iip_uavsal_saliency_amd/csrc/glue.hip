@@ -36,10 +36,18 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemK p) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[q][j] = 0.f;
     const size_t plane = (size_t)p.H * p.W;
-#pragma unroll
+    // NOT unrolled over (input channel, kernel row): fully unrolled, hipcc hoists all 81 input loads and the kernel
+    // needs > 256 VGPRs -- one wave per SIMD, 59 us; with the two outer loops rolled it is 80 VGPRs, six waves, 29 us
+#ifndef UAVSAL_STEM_UNROLL
+#define UAVSAL_STEM_UNROLL 1
+#endif
+#pragma unroll UAVSAL_STEM_UNROLL
     for (int ci = 0; ci < 3; ++ci) {
         const float mu = p.in_u8 ? p.mean[ci] : 0.f, sd = p.in_u8 ? p.stdv[ci] : 1.f;
-#pragma unroll
+#ifndef UAVSAL_STEM_UNROLL_KY
+#define UAVSAL_STEM_UNROLL_KY 1
+#endif
+#pragma unroll UAVSAL_STEM_UNROLL_KY
         for (int ky = 0; ky < 3; ++ky) {
             const int iy = oy * 2 - 1 + ky;
             const bool yok = iy >= 0 && iy < p.H;
