@@ -127,6 +127,12 @@ class Engine:
         self._scratch: Dict[tuple, torch.Tensor] = {}
         self._lane = 0
         self.plan = None
+        # everything below allocates on, or creates native objects for, the CURRENT device (the plan's error word, its
+        # `done` event, workspaces, occupancy queries): make that the engine's device, whatever the caller's is
+        with torch.cuda.device(self.device):
+            self._init_on_device(use_lanes)
+
+    def _init_on_device(self, use_lanes):
         # pass 1 sizes the shared scratch, pass 2 records the launches
         self._dry = True
         self._build()
@@ -240,10 +246,13 @@ class Engine:
             self._wcache[key] = (self._dev(P.pad_vec(s, n, 1.0)), self._dev(P.pad_vec(b, n, 0.0)))
         return self._wcache[key]
 
-    def _convw(self, conv, sl=None, gate_interleave=0, natural=False, dwproj=False):
+    def _convw(self, conv, sl=None, gate_interleave=0, natural=False, dwproj=False, k32=False):
         """`natural`: the pre-split LDS-DMA path takes the weights as [K step][Cout][hi 32 | lo 32] ('f16x3i');
-        `dwproj`: the split-fp16 depthwise -> projection kernel takes [K step of 16][Cout][hi 16 | lo 16] ('f16x3j')."""
+        `dwproj`: the split-fp16 depthwise -> projection kernel takes [K step of 16][Cout][hi 16 | lo 16] ('f16x3j');
+        `k32`: fp32 kernels with 32-float K stages (tiles 8 / 9; differs from 'f32' for 3x3 weights only)."""
         layout = "f16x3i" if natural else ("f16x3j" if dwproj and self.prec_name == "f16x3" else self.prec_name)
+        if k32 and layout == "f32" and conv.weight.shape[-1] == 3:
+            layout = "f32k32"
         key = ("w", id(conv), sl, layout, gate_interleave)
         if key not in self._wcache:
             w = conv.weight.detach()
@@ -360,9 +369,10 @@ class Engine:
         if a.t is None and not split:
             raise RuntimeError("%s: its input only exists as a split shadow but the GEMM is not eligible" % name)
         dwproj = int(self.lib.uavsal_conv_dwproj(C.byref(d)))
-        d.w = self._convw(conv, wslice, gate_interleave, natural=split, dwproj=dwproj != 0).data_ptr()
+        tile = int(self.lib.uavsal_conv_tile(C.byref(d)))
+        d.w = self._convw(conv, wslice, gate_interleave, natural=split, dwproj=dwproj != 0, k32=tile in (8, 9)).data_ptr()
         self.ops_meta[-1]["split"] = split
-        self.ops_meta[-1]["tile"] = int(self.lib.uavsal_conv_tile(C.byref(d)))
+        self.ops_meta[-1]["tile"] = tile
         self.ops_meta[-1]["streamk"] = int(self.lib.uavsal_conv_streamk_grid(C.byref(d)))
         self.ops_meta[-1]["dwproj"] = dwproj
         self._add(self.lib.uavsal_plan_add_conv, d, "plan_add_conv(%s)" % name)

@@ -208,7 +208,7 @@ class UAVSal(nn.Module):
         init_weights(self.fust_layer, "kaiming_normal", mode="fan_out")
         init_weights(self.conv_out_st, "kaiming_normal", mode="fan_out")
         self._engines: "OrderedDict[tuple, object]" = OrderedDict()
-        self._wshared: Dict[tuple, object] = {}      # packed device weights, shared by every engine
+        self._wshared: Dict[str, dict] = {}          # packed device weights per device, shared by its engines
         self._wversion = None
         if pre_model_path and os.path.exists(pre_model_path):
             # the reference's checkpoints are whole pickled models (model.py:339): resolved through the shim
@@ -264,7 +264,8 @@ class UAVSal(nn.Module):
                 self._wtensors = [t for k, t in self.state_dict(keep_vars=True).items()
                                   if not k.endswith("num_batches_tracked")]
                 self._wversion = self._weights_version()
-            elif self._weights_version() != self._wversion:      # param.data.copy_(...), an optimizer step, ...
+            elif self._weights_version() != self._wversion:      # in-place ops on the parameters (no_grad), optimizer steps
+                # (edits through `param.data` do NOT bump the version counter: call invalidate_engines() after those)
                 self._drop_engines()
                 return self._engine(device, n_seq, seq_len, H, W, ctx_mode, taps, in_dtype, sync_default)
         key = (str(device), n_seq, seq_len, H, W, self.time_dims if ctx_mode == "tile" else seq_len,
@@ -280,7 +281,7 @@ class UAVSal(nn.Module):
                          ctx_T=key[5], ctx_mode=ctx_mode, precision=self.precision, taps=taps,
                          in_dtype=in_dtype, use_graph=self.use_graph, fuse_dw=self.fuse_dw,
                          use_lanes=self.use_lanes, stream_k=self.stream_k, persistent=self.persistent_state,
-                         wcache=self._wshared)
+                         wcache=self._wshared.setdefault(str(torch.device(device)), {}))
             self._engines[key] = eng
         else:
             self._engines.move_to_end(key)

@@ -122,7 +122,9 @@ def conv_gemm(x, weight, scale=None, bias=None, act=L.ACT_NONE, res=None, out=No
     if split_in and not uses_split:
         raise RuntimeError("this shape / tile does not take the pre-split path")
     dwproj = int(lib.uavsal_conv_dwproj(C.byref(d))) != 0
-    wp = P.pack_conv_weight(weight, "f16x3i" if uses_split else ("f16x3j" if dwproj and prec == "f16x3" else prec)).to(x.device)
+    k32 = prec == "f32" and int(lib.uavsal_conv_tile(C.byref(d))) in (8, 9)     # 32-float K stages: 3x3 K order differs
+    wp = P.pack_conv_weight(weight, "f16x3i" if uses_split else ("f16x3j" if dwproj and prec == "f16x3" else
+                                                                 ("f32k32" if k32 else prec))).to(x.device)
     keep.append(wp)
     d.w = wp.data_ptr()
     L.check(lib.uavsal_conv_gemm(C.byref(d), _stream(x)), "uavsal_conv_gemm")

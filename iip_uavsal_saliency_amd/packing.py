@@ -36,7 +36,8 @@ def roundup(x: int, m: int) -> int:
 
 def pack_conv_weight(w: torch.Tensor, prec: str) -> torch.Tensor:
     """`w` [Cout, Cin, kh, kw] (kh=kw in {1,3}) -> packed byte tensor (uint8, 1-D) in the layout
-    `uavsal_conv_gemm` expects for `prec` in {'f32','bf16','bf16x3','f16x3'}, or 'f16x3i': the f16x3
+    `uavsal_conv_gemm` expects for `prec` in {'f32','bf16','bf16x3','f16x3'}, or 'f32k32': fp32 for the kernels
+    with 32-float K stages (uavsal_conv_tile 8 / 9: the 3x3 K order then has 32-channel blocks), or 'f16x3i': the f16x3
     values with the natural k order, hi and lo of one (K step, output channel) interleaved into one 128-byte
     line [Kpad/32][Npad][hi 32 | lo 32] (the pre-split LDS-DMA path, uavsal_conv_uses_split), or 'f16x3j' (below)."""
     w = w.detach().float().cpu()
@@ -44,6 +45,8 @@ def pack_conv_weight(w: torch.Tensor, prec: str) -> torch.Tensor:
     taps = kh * kw
     assert taps in (1, 9) and kh == kw
     kt = 16 if prec == "f32" else 32            # ('f16x3j' pads K to 32 too: the kernel walks Cin / 16 steps of it)
+    if prec == "f32k32":
+        prec = "f32"
     if taps == 9 and cin % 32:
         raise RuntimeError("3x3 dense conv needs Cin % 32 == 0")
     k = taps * cin

@@ -209,6 +209,11 @@ def main():
         # BASELINE configs[4]: 720x1280, 4 clips x 16 frames, two successive calls with carried state
         run_clips_case(ref_model, "clips_720x1280_C4_T16_two_calls", 720, 1280, 16, 4, calls=2, map_stride=5,
                        state_stride=211)
+    if not only or "demo" in only:
+        # Demo_Test.py's own call at its real size (Demo_Test.py:110-125: batch_size=4, time_dims=5 -> ONE forward of 20
+        # frames at 360x640): the context tiling quirk (model.py:357-361) and the cross-chunk temporal differences
+        # (model.py:194-198) at the shape the script runs, two successive calls with the carried state
+        run_case(ref_model, "e2e_360x640_B4T5_two_calls", 360, 640, 5, B=4, tap_stride=1999, state_stride=47, calls=2)
     if only and "base" not in only:
         return
     run_case(ref_model, "e2e_96x160_T4", 96, 160, 4)

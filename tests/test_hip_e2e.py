@@ -94,6 +94,35 @@ def test_forward_vs_reference_golden(hip_model, golden_dir, name, prec):
     assert all(e.streamk_clean() for e in hip_model._engines.values())
 
 
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+def test_demo_default_call_at_full_size_vs_reference_golden(hip_model, golden_dir, prec):
+    """Demo_Test.py:110-125 as it really runs: batch_size=4, time_dims=5 -> ONE forward of 20 frames at 360x640
+    (context prior tiled per model.py:357-361, temporal differences across the chunk borders per model.py:194-198),
+    then a second call fed with the returned state (Demo_Test.py:86) -- against the reference's own outputs."""
+    g = np.load(os.path.join(golden_dir, "e2e_360x640_B4T5_two_calls.npz"))
+    H, W, T, B = int(g["H"]), int(g["W"]), int(g["T"]), int(g["B"])
+    assert (H, W, T, B, int(g["calls"])) == (360, 640, 5, 4, 2)
+    n = B * T
+    state = None
+    for c in range(2):
+        x, cb = make_inputs(n, H, W, int(g["seed"]), t0=c * n)
+        taps = {}
+        out, st = _run_hip(hip_model, T, prec, x, cb, state, taps)
+        state = st
+        sfx = "" if c == 0 else f"_call{c}"
+        err = np.abs(out.numpy() - g["out" + sfx]).max()
+        lerr = np.abs(taps["logits"].cpu().numpy() - g["logits" + sfx]).max()
+        serr = np.abs(st.contiguous().view(-1).numpy()[::int(g["state_stride"])] - g["state" + sfx]).max()
+        print("demo default %s call %d: map %.3e logits %.3e state %.3e" % (prec, c, err, lerr, serr))
+        assert err <= MAP_TOL[prec], (prec, c, err)
+        assert lerr <= 2 * LOGIT_TOL[prec], (prec, c, lerr)
+        assert serr <= STATE_TOL[prec], (prec, c, serr)
+        if c == 0:      # the tiled context reaches the map through fucb_layer: frame k carries chunk k mod B
+            tap = taps["fust_in_cb"].cpu().contiguous().view(-1).numpy()[::int(g["tap_stride"])]
+            assert np.abs(tap - g["tap_fust_in_cb"]).max() <= TAP_REL[prec] * max(1.0, np.abs(g["tap_fust_in_cb"]).max())
+    assert all(e.streamk_clean() for e in hip_model._engines.values())
+
+
 def make_clips(C, T, H, W, seed=0, t0=0):
     """Clip c is seeded with seed + c (oracle/make_goldens.py clip_inputs, bench.py make_clips)."""
     h, w = H // 8, W // 8
@@ -395,8 +424,9 @@ def test_inputs_are_read_in_place_and_never_modified(hip_model):
 
 
 def test_in_place_weight_edit_rebuilds_the_plan(hip_model):
-    """Engines are built from the parameter values; an in-place edit (param.data.copy_, an optimizer step) is
-    detected by the version scan and the plan is rebuilt instead of silently using stale packed weights."""
+    """Engines are built from the parameter values; a version-bumping in-place edit (an op under no_grad, an optimizer
+    step, load_state_dict) is detected by the version scan and the plan is rebuilt instead of silently using stale
+    packed weights.  Edits through `param.data` do not bump the version: those need model.invalidate_engines()."""
     x, cb = make_inputs(4, 96, 160)
     hip_model.time_dims, hip_model.precision = 4, "f32"
     args = (x.cuda(), [cb[0].cuda(), cb[1].cuda()], None)

@@ -10,7 +10,9 @@ from iip_uavsal_saliency_amd import synth
 from oracle import uavsal_ref as R
 
 CASES = ["e2e_96x160_T4", "e2e_96x160_B4T5", "e2e_96x160_T4_two_calls", "e2e_72x104_T3"]
-BIG = ["e2e_288x512_T8"]
+BIG = ["e2e_288x512_T8",
+       # Demo_Test.py's own call at its real size: one forward of 4 x 5 = 20 frames at 360x640, twice (carried state)
+       "e2e_360x640_B4T5_two_calls"]
 
 
 def make_inputs(n, H, W, seed=0, t0=0):
