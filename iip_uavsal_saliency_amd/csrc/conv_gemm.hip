@@ -1456,54 +1456,6 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_gemm_h16_dma_k
     }
 }
 
-// Second launch of a K-split GEMM (dwproj_kernel's narrow instance, the 64x64 3x3 tile of the ConvTWA step): sums the
-// shares in a fixed order, then the epilogue -- BN, activation, residual, or the ConvTWA update (model_convlstm.py:
-// 276-292: gate = sigmoid(sum + W_x x_t), h_t = gate x_t + (1 - gate) h_{t-1}) -- and the split shadow.
-// One thread per (row, 4 output channels).
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvK p, float acc_scale) {
-    const int groups = (p.Cout + 3) >> 2;
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long long)p.M * groups) return;
-    const int m = (int)(idx / groups), gn = (int)(idx - (long long)m * groups) * 4;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < p.ksplit; ++k) v += *reinterpret_cast<const f32x4*>(p.kpart + ((size_t)k * p.M + m) * p.Npad + gn);
-    const int img = m / p.HW, pix = m - img * p.HW;
-    float* o = p.out + ((long long)img * p.o_is + pix) * p.ldc + gn;
-    const float* rs = p.res ? p.res + ((long long)img * p.r_is + pix) * p.ldr + gn : nullptr;
-    const bool twa = p.epi == UAVSAL_EPI_TWA;
-    const float* ax = twa ? p.aux + ((long long)img * p.x_is + pix) * p.ldx + gn : nullptr;
-    const float* hp = twa ? p.a + ((long long)img * p.a_is + pix) * p.lda + gn : nullptr;
-    const bool vec = gn + 3 < p.Cout && !(p.ldc & 3) && !((size_t)p.out & 15) && (!p.res || (!(p.ldr & 3) && !((size_t)p.res & 15)));
-    f32x4 r;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const bool okc = gn + c < p.Cout;
-        if (twa) {
-            const float z = v[c] * acc_scale + (okc ? ax[c] : 0.f);
-            const float gate = 1.f / (1.f + expf(-z));
-            r[c] = okc ? gate * rs[c] + (1.f - gate) * hp[c] : 0.f;
-        } else {
-            const float sc = (p.scale && okc ? p.scale[gn + c] : 1.f) * acc_scale, bi = p.scale && okc ? p.bias[gn + c] : 0.f;
-            r[c] = apply_act(fmaf(v[c], sc, bi), p.act);
-            if (rs && okc) r[c] += rs[c];
-        }
-    }
-    if (vec) {
-        *reinterpret_cast<f32x4*>(o) = r;
-        if (p.out_sp) uavsal_store_split4(p.out_sp + ((long long)img * p.o_is + pix) * p.ldos, gn, r);
-    } else {
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-            if (gn + c < p.Cout) o[c] = r[c];
-    }
-}
-
-int launch_splitk_reduce(const ConvK& k, float acc_scale, hipStream_t stream) {
-    const long long items = (long long)k.M * ((k.Cout + 3) / 4);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream, k, acc_scale);
-    return uavsal_launch_status();
-}
-
 // resident workgroups per CU for one kernel instantiation (cached; queried once, outside any capture)
 template <typename K>
 int resident_grid(K kernel, int smem, int threads = 256) {
@@ -1821,12 +1773,26 @@ int pick_tile(long long M, int Cout, int prec) {
 }  // namespace
 
 static int effective_tile(const uavsal_conv_desc* d) {
-    int tile = (d->tile >= 1 && d->tile <= 9) ? d->tile
+    int tile = (d->tile >= 1 && d->tile <= 10) ? d->tile
                                              : pick_tile((long long)d->H * d->W * d->n_img, d->Cout, d->prec);
+    if (tile == 10 && !uavsal_f32_k32_eligible(d, 10)) tile = 8;
     if ((tile == 8 || tile == 9) && !uavsal_f32_k32_eligible(d, tile)) tile = tile == 9 ? 7 : 1;   // full-line K stages
     // automatic choice: the 128 x 128 launches that do not take the stream-K path move to the kernel with 32-float K
     // stages (conv_gemm_k32.hip); UAVSAL_K32=0 keeps the 16-float one, UAVSAL_K32=9 picks the 256 x 128 instance
     // where it still fills the chip
+    // ... and launches with too few tiles for the chip and a long K walk take it with K split over several workgroups
+    // per tile (uavsal_f32_k32_ksplit): the ConvTWA step (UAVSAL_K32_SPLITK=1, the default), every such conv (=2), none (=0)
+    if (d->tile == 0 && tile == 4 && d->prec == UAVSAL_PREC_F32 && d->sk_ws && d->sk_ws_bytes > 65536) {
+        static const int k32_mode = [] { const char* e = getenv("UAVSAL_K32"); return e ? atoi(e) : 1; }();
+        static const int sk_mode = [] { const char* e = getenv("UAVSAL_K32_SPLITK"); return e ? atoi(e) : 1; }();
+        const bool want = sk_mode == 2 ? (d->epi == UAVSAL_EPI_AFFINE || d->epi == UAVSAL_EPI_TWA) : (sk_mode == 1 && d->epi == UAVSAL_EPI_TWA);
+        if (k32_mode && want && uavsal_f32_k32_eligible(d, 8)) {
+            const long long M = (long long)d->H * d->W * d->n_img;
+            const int npad = (d->Cout + 31) / 32 * 32;
+            const int ksp = uavsal_f32_k32_ksplit(((M + 127) / 128) * ((d->Cout + 127) / 128), d->taps * d->Cin / 32);
+            if (ksp > 1 && (long long)ksp * M * npad * 4 <= d->sk_ws_bytes - 65536 && !(d->Cout & 3) && !(d->ldc & 3)) tile = 8;
+        }
+    }
     if (d->tile == 0 && tile == 1 && d->prec == UAVSAL_PREC_F32) {
         static const int k32_mode = [] { const char* e = getenv("UAVSAL_K32"); return e ? atoi(e) : 1; }();
         if (k32_mode && uavsal_f32_k32_eligible(d, 8) && d->epi == UAVSAL_EPI_AFFINE &&
@@ -1970,7 +1936,7 @@ extern "C" int uavsal_conv_gemm(const uavsal_conv_desc* d, uavsal_stream_t strea
             return t1 ? SkSmall::launch<1>(k, G, s) : SkSmall::launch<9>(k, G, s);
         }
     }
-    if (tile == 8 || tile == 9) return uavsal_launch_f32_k32(k, d->taps, tile, s);
+    if (tile >= 8 && tile <= 10) return uavsal_launch_f32_k32(k, d->taps, tile, s);
     switch (d->prec) {
         case UAVSAL_PREC_F32:    // the fused producer needs register staging: use the generic kernel
             return k.dw_w ? launch_prec<UAVSAL_PREC_F32>(k, d->taps, tile, s) : launch_f32(k, d->taps, tile, s);

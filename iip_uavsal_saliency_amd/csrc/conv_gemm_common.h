@@ -40,6 +40,7 @@ struct ConvK {
 // conv_gemm_k32.hip: fp32 LDS-DMA GEMM with 128-byte (32-float) K stages; tile = 8 (128 x 128) or 9 (256 x 128)
 int uavsal_launch_f32_k32(const uavsal_gemm::ConvK& k, int taps, int tile, hipStream_t stream);
 bool uavsal_f32_k32_eligible(const uavsal_conv_desc* d, int tile);
+int uavsal_f32_k32_ksplit(long long tiles, int stages);
 
 namespace {
 using uavsal_gemm::ConvK;
@@ -245,5 +246,53 @@ __device__ __attribute__((aligned(16))) float g_zero_row[UAVSAL_DWPROJ_MAX_C + 1
 #ifndef UAVSAL_GEMM_PREFETCH
 #define UAVSAL_GEMM_PREFETCH 2
 #endif
+
+// Second launch of a K-split GEMM (dwproj_kernel's narrow instance, the 64x64 3x3 tile of the ConvTWA step): sums the
+// shares in a fixed order, then the epilogue -- BN, activation, residual, or the ConvTWA update (model_convlstm.py:
+// 276-292: gate = sigmoid(sum + W_x x_t), h_t = gate x_t + (1 - gate) h_{t-1}) -- and the split shadow.
+// One thread per (row, 4 output channels).
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvK p, float acc_scale) {
+    const int groups = (p.Cout + 3) >> 2;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)p.M * groups) return;
+    const int m = (int)(idx / groups), gn = (int)(idx - (long long)m * groups) * 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < p.ksplit; ++k) v += *reinterpret_cast<const f32x4*>(p.kpart + ((size_t)k * p.M + m) * p.Npad + gn);
+    const int img = m / p.HW, pix = m - img * p.HW;
+    float* o = p.out + ((long long)img * p.o_is + pix) * p.ldc + gn;
+    const float* rs = p.res ? p.res + ((long long)img * p.r_is + pix) * p.ldr + gn : nullptr;
+    const bool twa = p.epi == UAVSAL_EPI_TWA;
+    const float* ax = twa ? p.aux + ((long long)img * p.x_is + pix) * p.ldx + gn : nullptr;
+    const float* hp = twa ? p.a + ((long long)img * p.a_is + pix) * p.lda + gn : nullptr;
+    const bool vec = gn + 3 < p.Cout && !(p.ldc & 3) && !((size_t)p.out & 15) && (!p.res || (!(p.ldr & 3) && !((size_t)p.res & 15)));
+    f32x4 r;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const bool okc = gn + c < p.Cout;
+        if (twa) {
+            const float z = v[c] * acc_scale + (okc ? ax[c] : 0.f);
+            const float gate = 1.f / (1.f + expf(-z));
+            r[c] = okc ? gate * rs[c] + (1.f - gate) * hp[c] : 0.f;
+        } else {
+            const float sc = (p.scale && okc ? p.scale[gn + c] : 1.f) * acc_scale, bi = p.scale && okc ? p.bias[gn + c] : 0.f;
+            r[c] = apply_act(fmaf(v[c], sc, bi), p.act);
+            if (rs && okc) r[c] += rs[c];
+        }
+    }
+    if (vec) {
+        *reinterpret_cast<f32x4*>(o) = r;
+        if (p.out_sp) uavsal_store_split4(p.out_sp + ((long long)img * p.o_is + pix) * p.ldos, gn, r);
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (gn + c < p.Cout) o[c] = r[c];
+    }
+}
+
+int launch_splitk_reduce(const ConvK& k, float acc_scale, hipStream_t stream) {
+    const long long items = (long long)k.M * ((k.Cout + 3) / 4);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream, k, acc_scale);
+    return uavsal_launch_status();
+}
 
 }  // namespace

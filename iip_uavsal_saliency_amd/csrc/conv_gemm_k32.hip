@@ -21,6 +21,32 @@
 #define UAVSAL_EPI_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #include "conv_gemm_common.h"
 
+// Diagnostic builds only (tools/build_probe.sh -> libuavsal_hip_probe.so; the product build has none of this):
+//   -DUAVSAL_PROBE: act = 100 + bits {1 no output store, 2 no MFMAs, 4 no DMA requests, 8 no fragment reads,
+//                   16 no epilogue} times the kernel with parts compiled out (tools/k32_probe.py parts);
+//   -DUAVSAL_K32_STAMPS: every wave sums the cycles (s_memtime) it spends waiting at the stage head, in the stage
+//                   body, between the K loop and the epilogue, and in the epilogue, into p.kpart[0..4] (u64).
+#ifdef UAVSAL_PROBE
+#undef UAVSAL_STORE_OK
+#define UAVSAL_STORE_OK(act) (((act) < 100) || !(((act) - 100) & 1))
+#endif
+#ifdef UAVSAL_K32_STAMPS
+#define K32_STAMP(var) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); var += t_ - t_prev; t_prev = t_; }
+#else
+#define K32_STAMP(var)
+#endif
+
+// Experiment knobs (tools/build_probe.sh builds one library per setting; defaults = the product build)
+#ifndef K32_PRIO
+#define K32_PRIO 0          // 1: the workgroup in the even wave slot of a SIMD runs at raised priority (its CU-mate fills the gaps)
+#endif
+#ifndef K32_STAGGER
+#define K32_STAGGER 0       // N > 0: the workgroup in the odd wave slot starts N x 64 cycles late (s_sleep)
+#endif
+#ifndef K32_FRAG
+#define K32_FRAG 0          // 1: pin the fragment reads of sub-step u + 1 behind the first MFMAs of sub-step u
+#endif
+
 namespace {
 
 template <int WAVES_M, int WAVES_N, int TAPS, int MINW>
@@ -47,10 +73,30 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW) void conv_gemm_f32_k3
     const int lane = tid & 63;
     const int wm = wave_u / WAVES_N, wn = wave_u - wm * WAVES_N;
     const int lr = lane & 31, lh = lane >> 5;
+#ifdef UAVSAL_PROBE
+    const int pr_bits = p.act >= 100 ? p.act - 100 : 0;
+    const bool pr_mul = !(pr_bits & 2), pr_dma = !(pr_bits & 4), pr_frag = !(pr_bits & 8), pr_epi = !(pr_bits & 16);
+#else
+    constexpr bool pr_mul = true, pr_dma = true, pr_frag = true, pr_epi = true;
+#endif
+#ifdef UAVSAL_K32_STAMPS
+    unsigned long long t_prev = __builtin_amdgcn_s_memtime(), c_wait = 0, c_body = 0, c_tail = 0, c_epi = 0;
+    const unsigned long long t_begin = t_prev;
+#endif
     const uavsal_tile_walk walk = xcd_tile_walk(blockIdx.x, gridDim.x, p.nblk);
     int tile = walk.tile;
     if (tile >= walk.end) return;
     int m0 = 0, n0 = 0;
+#if K32_PRIO || K32_STAGGER
+    // HW_REG_HW_ID[3:0] = wave slot on the SIMD: the two co-resident workgroups of a CU sit in different slots
+    const int slot_odd = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1;
+#if K32_PRIO
+    if (!slot_odd) __builtin_amdgcn_s_setprio(2);
+#endif
+#if K32_STAGGER
+    if (slot_odd) __builtin_amdgcn_s_sleep(K32_STAGGER);
+#endif
+#endif
 
     // request coordinates of this lane: row (tid >> 3) + it * RPI of a panel, physical slot tid & 7
     const int r8 = tid >> 3;
@@ -59,10 +105,19 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW) void conv_gemm_f32_k3
     const float* b_ptr[B_IT];
     long long a_base[A_IT];                              // 3x3: element offset of the row's centre pixel ...
     int a_taps[A_IT];                                    // ... and which of its nine taps lie inside the image
-    const int nst = p.Kpad / KT;
+    const int nst_all = p.Kpad / KT;
+    int nst = nst_all;                                   // stages of the current tile (a share of them when K is split)
+    int ks = 0;                                          // ... and which share
     int it_tap = 0, it_cb = 0;                           // 3x3: tap / channel block of the next stage to request
 
     auto setup_tile = [&](int t) {
+        int s0 = 0;                                      // K split: t = tile * ksplit + share
+        if (p.ksplit > 1) {
+            ks = t % p.ksplit;
+            t /= p.ksplit;
+            s0 = ks * nst_all / p.ksplit;
+            nst = (ks + 1) * nst_all / p.ksplit - s0;
+        }
         const int tile_m = t / p.tiles_n;
         const int tile_n = t - tile_m * p.tiles_n;
         m0 = tile_m * BM;
@@ -73,7 +128,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW) void conv_gemm_f32_k3
             const bool ok = m < p.M;
             if (TAPS == 1) {
                 // rows past M walk a row of zeros (their accumulators are never stored)
-                a_ptr[it] = ok ? p.a + row_off(m, p.HW, p.a_is, p.contig) * p.lda + lc * 4 : g_zero_row + lc * 4;
+                a_ptr[it] = (ok ? p.a + row_off(m, p.HW, p.a_is, p.contig) * p.lda + lc * 4 : g_zero_row + lc * 4) + s0 * KT;
             } else {
                 const int mm = ok ? m : 0;
                 const int img = mm / p.HW;
@@ -93,9 +148,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW) void conv_gemm_f32_k3
         for (int it = 0; it < B_IT; ++it) {
             // weight rows past Npad re-read the last real row (those columns are never stored)
             const int nn = min(n0 + r8 + it * RPI, p.Npad - 1);
-            b_ptr[it] = reinterpret_cast<const float*>(p.w) + (size_t)nn * p.Kpad + lc * 4;
+            b_ptr[it] = reinterpret_cast<const float*>(p.w) + (size_t)nn * p.Kpad + lc * 4 + s0 * KT;
         }
-        it_tap = 0; it_cb = 0;
+        it_cb = s0 / 9; it_tap = s0 - it_cb * 9;         // (3x3: stage s = channel block s / 9, tap s % 9)
     };
 
     // request r (compile-time) of the next stage, into the ring stage at `st`
@@ -110,6 +165,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW) void conv_gemm_f32_k3
         }
     };
     auto issue_one = [&](int r, char* st) {
+        if (!pr_dma) return;
         if (r < A_IT) {
             const float* src;
             if (TAPS == 1) {
@@ -137,6 +193,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW) void conv_gemm_f32_k3
     f32x16 acc[WM][WN];
     f32x4 fa[2][WM], fb[2][WN];
     auto ldfrag = [&](const char* st, int u, int buf) {
+        if (!pr_frag) return;
         const int so = ((2 * u + lh) ^ sw) * 16;
 #pragma unroll
         for (int i = 0; i < WM; ++i) fa[buf][i] = *reinterpret_cast<const f32x4*>(st + a_row + i * 32 * 128 + so);
@@ -157,20 +214,28 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW) void conv_gemm_f32_k3
 #pragma unroll
                 for (int j = 0; j < WN; ++j) {
                     const f32x4 av = fa[u & 1][i], bv = fb[u & 1][j];
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[i][j], 0, 0, 0);
+                    if (pr_mul) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[i][j], 0, 0, 0);
+                    }
                     const int g = (u * WM + i) * WN + j;
                     if (ISSUE && g < LPT) issue_one(g, ist);
                 }
+#if K32_FRAG
+            // order within the sub-step: 2 MFMAs, the 4 fragment reads of the next sub-step, the other 14 MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, WM + WN, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * WM * WN - 2, 0);
+#endif
         }
     };
 
     setup_tile(tile);
     issue_stage(smem);
     while (true) {
-        const int m0c = m0, n0c = n0;
+        const int m0c = m0, n0c = n0, ksc = ks;
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -184,12 +249,16 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW) void conv_gemm_f32_k3
         for (; kt + 1 < nst; ++kt) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            K32_STAMP(c_wait)
             char* st = smem + (kt & 1) * STAGE;
             stage(std::true_type{}, st, smem + ((kt & 1) ^ 1) * STAGE);
+            K32_STAMP(c_body)
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        K32_STAMP(c_wait)
         stage(std::false_type{}, smem + (kt & 1) * STAGE, nullptr);
+        K32_STAMP(c_body)
 
         const bool has_next = (tile + walk.stride) < walk.end;
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // every wave is past its reads of the ring
@@ -198,18 +267,324 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW) void conv_gemm_f32_k3
             setup_tile(tile);
             issue_stage(smem);                   // next tile's stage 0 -> slot 0; the epilogue stages through slot 1
         }
-        UAVSAL_GEMM_EPILOGUE(1.0f, (smem + STAGE), false)
+        K32_STAMP(c_tail)
+        if (p.ksplit > 1) {
+            // a K share: raw sums -> p.kpart[share][M][Npad] (splitk_reduce_kernel adds the shares in a fixed order and
+            // applies the epilogue).  Barrier-free: every wave passes its 32 x 32 blocks through its own 4 KB of slot 1
+            float* stg = reinterpret_cast<float*>(smem + STAGE) + wave_u * 1024;
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) stg[((q & 3) + 8 * (q >> 2) + 4 * lh) * 32 + lr] = acc[i][j][q];
+                    const int gn = n0c + (wn * WN + j) * 32 + (lane & 7) * 4;
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int row = (lane >> 3) + it * 8;
+                        const int gm = m0c + (wm * WM + i) * 32 + row;
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * 32 + (lane & 7) * 4);
+                        if (gm < p.M && gn < p.Npad)
+                            *reinterpret_cast<f32x4*>(p.kpart + ((size_t)ksc * p.M + gm) * p.Npad + gn) = v;
+                    }
+                }
+        } else if (pr_epi) UAVSAL_GEMM_EPILOGUE(1.0f, (smem + STAGE), false)
+        K32_STAMP(c_epi)
         if (!has_next) break;
     }
+#ifdef UAVSAL_K32_STAMPS
+    if (lane == 0 && p.kpart) {
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(p.kpart);
+        atomicAdd(dbg + 0, c_wait); atomicAdd(dbg + 1, c_body); atomicAdd(dbg + 2, c_tail); atomicAdd(dbg + 3, c_epi);
+        atomicAdd(dbg + 4, __builtin_amdgcn_s_memtime() - t_begin); atomicAdd(dbg + 5, 1ull);
+    }
+#endif
 }
 
-template <int WAVES_M, int WAVES_N, int MINW>
+
+// ---------------------------------------------------------------------------------------------------------
+// The same GEMM as ONE continuous stream of K stages over all the tiles of a workgroup ("flat pipeline").
+//   * one barrier per stage, placed where nothing is pending: in the middle of the stage's LAST K sub-step.  By then
+//     the requests of stage g + 1 are a whole stage old (`vmcnt(0)` costs nothing) and every fragment of stage g is in
+//     registers, so the barrier at once publishes stage g + 1 (RAW) and frees the slot of stage g (WAR);
+//   * behind it the wave reads the first fragments of stage g + 1 -- they land under the remaining MFMAs of stage g,
+//     there is no read bubble at a stage head -- and requests stage g + 2 into the freed slot: a two-slot ring that is
+//     a full stage ahead;
+//   * the stream runs across tile boundaries: while a tile's epilogue stores, the next tile's first two stages are in
+//     flight and its first fragments are already in registers (the epilogue stages through its own 16 KB);
+//   * fragment reads are `ds_read_b128` in inline asm with counted `lgkmcnt` waits (hipcc re-merges the two fragment
+//     sets of a compiler-scheduled loop into one and waits `lgkmcnt(0)` in front of every sub-step).
+template <int WAVES_M, int WAVES_N, int TAPS, int MINW>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW) void conv_gemm_f32_k32p_kernel(const ConvK p) {
+    constexpr int WM = 2, WN = 2;
+    constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32;
+    constexpr int KT = 32;
+    constexpr int NW = WAVES_M * WAVES_N, NT = NW * 64;
+    constexpr int RPI = NT / 8;
+    constexpr int A_IT = BM / RPI, B_IT = BN / RPI, LPT = A_IT + B_IT;
+    constexpr int APAN = BM * 128, BPAN = BN * 128, STAGE = APAN + BPAN;
+    static_assert(BM % RPI == 0 && BN % RPI == 0 && RPI % 16 == 0, "panels divide over the workgroup");
+    static_assert(LPT % 2 == 0, "requests are issued behind two MFMA groups");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    typedef __attribute__((address_space(3))) char* lds_cp;
+
+    const int tid = threadIdx.x;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int wm = wave_u / WAVES_N, wn = wave_u - wm * WAVES_N;
+    const int lr = lane & 31, lh = lane >> 5;
+#ifdef UAVSAL_PROBE
+    const int pr_bits = p.act >= 100 ? p.act - 100 : 0;
+    const bool pr_mul = !(pr_bits & 2), pr_dma = !(pr_bits & 4), pr_frag = !(pr_bits & 8), pr_epi = !(pr_bits & 16);
+#else
+    constexpr bool pr_mul = true, pr_dma = true, pr_frag = true, pr_epi = true;
+#endif
+    const uavsal_tile_walk walk = xcd_tile_walk(blockIdx.x, gridDim.x, p.nblk);
+    if (walk.tile >= walk.end) return;
+#if K32_PRIO
+    if (!(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1)) __builtin_amdgcn_s_setprio(2);
+#endif
+#ifdef UAVSAL_K32_STAMPS      // in-kernel clock: shader cycles (s_memtime) per 100 MHz tick (s_memrealtime) over the kernel
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime(), r_begin = __builtin_amdgcn_s_memrealtime();
+#endif
+    const int nst = p.Kpad / KT;
+
+    // ---- request side: the stream of stages (tile by tile) still to be requested
+    const int r8 = tid >> 3;
+    const int lc = (tid & 7) ^ ((r8 >> 1) & 7);
+    const float* a_ptr[A_IT];
+    const float* b_ptr[B_IT];
+    long long a_base[A_IT];
+    int a_taps[A_IT];
+    int rq_tile = walk.tile, rq_kt = 0, it_tap = 0, it_cb = 0;
+    long long tap_off = 0;
+    int tap_bit = 0;
+    auto setup_requests = [&](int t) {
+        const int tile_m = t / p.tiles_n;
+        const int rm0 = tile_m * BM, rn0 = (t - tile_m * p.tiles_n) * BN;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const int m = rm0 + r8 + it * RPI;
+            const bool ok = m < p.M;
+            if (TAPS == 1) {
+                a_ptr[it] = ok ? p.a + row_off(m, p.HW, p.a_is, p.contig) * p.lda + lc * 4 : g_zero_row + lc * 4;
+            } else {
+                const int mm = ok ? m : 0;
+                const int img = mm / p.HW;
+                const int pix = mm - img * p.HW;
+                const int y = pix / p.W, x = pix - y * p.W;
+                a_base[it] = ((long long)img * p.a_is + pix) * p.lda + lc * 4;
+                int mask = 0;
+#pragma unroll
+                for (int tp = 0; tp < 9; ++tp) {
+                    const int yy = y + tp / 3 - 1, xx = x + tp % 3 - 1;
+                    if (ok && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) mask |= 1 << tp;
+                }
+                a_taps[it] = mask;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            const int nn = min(rn0 + r8 + it * RPI, p.Npad - 1);
+            b_ptr[it] = reinterpret_cast<const float*>(p.w) + (size_t)nn * p.Kpad + lc * 4;
+        }
+        it_tap = 0; it_cb = 0;
+    };
+    // moves to the next stage of the stream; false when the stream is exhausted
+    auto next_request = [&]() -> bool {
+        if (rq_kt == nst) {
+            rq_tile += walk.stride;
+            rq_kt = 0;
+            if (rq_tile < walk.end) setup_requests(rq_tile);
+        }
+        if (rq_tile >= walk.end) return false;
+        ++rq_kt;
+        if (TAPS == 9) {
+            const int ty = (it_tap * 11) >> 5;
+            tap_off = (long long)((ty - 1) * p.W + (it_tap - ty * 3 - 1)) * p.lda + it_cb * KT;
+            tap_bit = it_tap;
+            if (++it_tap == 9) { it_tap = 0; ++it_cb; }
+        }
+        return true;
+    };
+    auto issue_one = [&](int r, char* st) {
+        if (!pr_dma) return;
+        if (r < A_IT) {
+            const float* src;
+            if (TAPS == 1) {
+                src = a_ptr[r];
+                a_ptr[r] += KT;
+            } else {
+                src = ((a_taps[r] >> tap_bit) & 1) ? p.a + a_base[r] + tap_off : g_zero16;
+            }
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(st + (r * RPI + wave_u * 8) * 128), 16, 0, 0);
+        } else {
+            const int it = r - A_IT;
+            __builtin_amdgcn_global_load_lds((gptr_t)b_ptr[it], (lptr_t)(st + APAN + (it * RPI + wave_u * 8) * 128), 16, 0, 0);
+            b_ptr[it] += KT;
+        }
+    };
+
+    // ---- compute side
+    const int sw = (lr >> 1) & 7;
+    const unsigned lds0 = (unsigned)(size_t)(lds_cp)smem;
+    const unsigned a_row = lds0 + (wm * WM * 32 + lr) * 128, b_row = lds0 + APAN + (wn * WN * 32 + lr) * 128;
+    f32x16 acc[WM][WN];
+    f32x4 fa[2][WM], fb[2][WN];
+    // fragments of K sub-step u of the stage in ring slot `slot` -> set `buf` (WM + WN reads, not waited for)
+    auto ldfrag = [&](int slot, int u, int buf) {
+        if (!pr_frag) return;
+        const unsigned so = slot * STAGE + (((2 * u + lh) ^ sw) << 4);
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[buf][i]) : "v"(a_row + so), "n"(i * 32 * 128));
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[buf][j]) : "v"(b_row + so), "n"(j * 32 * 128));
+    };
+    // set `buf` has landed when at most WM + WN younger LDS reads (the next set) are outstanding / when none is
+    auto frag_wait_next = [&](int buf) {
+        if (!pr_frag) return;
+        asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(fa[buf][0]), "+v"(fa[buf][1]), "+v"(fb[buf][0]), "+v"(fb[buf][1])
+                     : "n"(WM + WN));
+    };
+    auto frag_wait_all = [&](int buf) {
+        if (!pr_frag) return;
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[buf][0]), "+v"(fa[buf][1]), "+v"(fb[buf][0]), "+v"(fb[buf][1]));
+    };
+    auto mma = [&](int buf, int i, int j) {
+        if (!pr_mul) return;
+        const f32x4 av = fa[buf][i], bv = fb[buf][j];
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[i][j], 0, 0, 0);
+    };
+
+    // lead-in: stage 0 -> slot 0, published; stage 1 -> slot 1; first fragments
+    setup_requests(rq_tile);
+    if (next_request()) {
+#pragma unroll
+        for (int r = 0; r < LPT; ++r) issue_one(r, smem);
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if (next_request()) {
+#pragma unroll
+        for (int r = 0; r < LPT; ++r) issue_one(r, smem + STAGE);
+    }
+    ldfrag(0, 0, 0);
+
+    int g = 0;                                           // stages done so far: stage g lives in slot g & 1
+    for (int tile = walk.tile; tile < walk.end; tile += walk.stride) {
+        const int tile_m = tile / p.tiles_n;
+        const int m0c = tile_m * BM, n0c = (tile - tile_m * p.tiles_n) * BN;
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+        const bool last_tile = tile + walk.stride >= walk.end;
+        float sc[WN], bi[WN];
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {       // (scale / bias are padded to Npad; columns past it are never stored)
+            const int c = min(n0c + (wn * WN + j) * 32 + lr, p.Npad - 1);
+            asm volatile("global_load_dword %0, %1, off" : "=v"(sc[j]) : "v"(p.scale + c) : "memory");
+            asm volatile("global_load_dword %0, %1, off" : "=v"(bi[j]) : "v"(p.bias + c) : "memory");
+        }
+        for (int kt = 0; kt < nst; ++kt, ++g) {
+            const int slot = g & 1;
+            // sub-steps 0..2: read the next sub-step's fragments, then multiply this one
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                ldfrag(slot, u + 1, (u + 1) & 1);
+                frag_wait_next(u & 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) mma(u & 1, i, j);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // sub-step 3, first half
+            frag_wait_all(1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(1, 0, 0);
+            mma(1, 0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            // the stage's one barrier: requests of stage g + 1 landed (a stage old), all fragments of stage g are in
+            // registers -> stage g + 1 is published and slot g & 1 is free
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            const bool more = kt + 1 < nst || !last_tile;
+            if (more) ldfrag(slot ^ 1, 0, 0);
+            const bool req = next_request();             // stage g + 2 -> slot g & 1
+            __builtin_amdgcn_sched_barrier(0);
+            mma(1, 1, 0);
+            if (req) {
+#pragma unroll
+                for (int r = 0; r < LPT / 2; ++r) issue_one(r, smem + slot * STAGE);
+            }
+            mma(1, 1, 1);
+            if (req) {
+#pragma unroll
+                for (int r = LPT / 2; r < LPT; ++r) issue_one(r, smem + slot * STAGE);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- epilogue (folded BN, ReLU6 / none, optional residual), barrier-free: every wave passes its four
+        // 32 x 32 accumulator blocks through its own 4 KB of LDS and stores them as 128-byte row segments.  The
+        // BN scale / bias of the tile's columns were fetched at the tile's start by loads hipcc does not see (a
+        // compiler-visible load left pending on some path makes it drain vmcnt(0) inside the K loop).
+        if (pr_epi) {
+            float* stg = reinterpret_cast<float*>(smem + 2 * STAGE) + wave_u * 1024;
+            const float lo = p.act == UAVSAL_ACT_RELU6 ? 0.f : -3.0e38f;
+            const float hi = p.act == UAVSAL_ACT_RELU6 ? 6.f : 3.0e38f;
+            asm volatile("" : "+v"(sc[0]), "+v"(sc[1]), "+v"(bi[0]), "+v"(bi[1]));      // landed: older than every stage
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int r = (q & 3) + 8 * (q >> 2) + 4 * lh;
+                        stg[r * 32 + lr] = __builtin_amdgcn_fmed3f(fmaf(acc[i][j][q], sc[j], bi[j]), lo, hi);
+                    }
+                    const int gn = n0c + (wn * WN + j) * 32 + (lane & 7) * 4;
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int row = (lane >> 3) + it * 8;
+                        const int gm = m0c + (wm * WM + i) * 32 + row;
+                        f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * 32 + (lane & 7) * 4);
+                        if (gm < p.M && gn < p.Cout) {
+                            const long long ro = row_off(gm, p.HW, p.o_is, p.contig);
+                            if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + row_off(gm, p.HW, p.r_is, p.contig) * p.ldr + gn);
+                            if (UAVSAL_STORE_OK(p.act)) *reinterpret_cast<f32x4*>(p.out + ro * p.ldc + gn) = v;
+                        }
+                    }
+                }
+        }
+    }
+#ifdef UAVSAL_K32_STAMPS
+    if (lane == 0 && p.kpart) {
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(p.kpart);
+        atomicAdd(dbg + 4, __builtin_amdgcn_s_memtime() - t_begin);
+        atomicAdd(dbg + 5, 1ull);
+        atomicAdd(dbg + 6, __builtin_amdgcn_s_memrealtime() - r_begin);
+    }
+#endif
+}
+
+template <int WAVES_M, int WAVES_N, int MINW, bool FLAT = false>
 int launch_k32(const ConvK& k0, int taps, hipStream_t stream) {
     constexpr int BM = WAVES_M * 64, BN = WAVES_N * 64, NT = WAVES_M * WAVES_N * 64;
-    constexpr int SMEM = 2 * (BM + BN) * 128;
+    constexpr int SMEM = 2 * (BM + BN) * 128 + (FLAT ? 32 * BN * 4 : 0);
     ConvK k = k0;
     k.tiles_n = (k.Cout + BN - 1) / BN;
     k.nblk = ((k.M + BM - 1) / BM) * k.tiles_n;
+    k.ksplit = 1;
     auto cap_of = [](auto kernel) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         int per_cu = 0, cus = 0, dev = 0;
@@ -218,29 +593,67 @@ int launch_k32(const ConvK& k0, int taps, hipStream_t stream) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, NT, SMEM) != hipSuccess || per_cu <= 0) per_cu = 1;
         return per_cu * cus;
     };
-    if (taps == 1) {
-        static const int cap = cap_of(conv_gemm_f32_k32_kernel<WAVES_M, WAVES_N, 1, MINW>);
-        const int grid = k.nblk < cap ? k.nblk : cap;
-        hipLaunchKernelGGL((conv_gemm_f32_k32_kernel<WAVES_M, WAVES_N, 1, MINW>), dim3(grid), dim3(NT), SMEM, stream, k);
+    if constexpr (FLAT) {
+        if (taps == 1) {
+            static const int cap = cap_of(conv_gemm_f32_k32p_kernel<WAVES_M, WAVES_N, 1, MINW>);
+            const int grid = k.nblk < cap ? k.nblk : cap;
+            hipLaunchKernelGGL((conv_gemm_f32_k32p_kernel<WAVES_M, WAVES_N, 1, MINW>), dim3(grid), dim3(NT), SMEM, stream, k);
+        } else {
+            static const int cap = cap_of(conv_gemm_f32_k32p_kernel<WAVES_M, WAVES_N, 9, MINW>);
+            const int grid = k.nblk < cap ? k.nblk : cap;
+            hipLaunchKernelGGL((conv_gemm_f32_k32p_kernel<WAVES_M, WAVES_N, 9, MINW>), dim3(grid), dim3(NT), SMEM, stream, k);
+        }
     } else {
-        static const int cap = cap_of(conv_gemm_f32_k32_kernel<WAVES_M, WAVES_N, 9, MINW>);
+        static const int cap1 = cap_of(conv_gemm_f32_k32_kernel<WAVES_M, WAVES_N, 1, MINW>);
+        static const int cap9 = cap_of(conv_gemm_f32_k32_kernel<WAVES_M, WAVES_N, 9, MINW>);
+        const int cap = taps == 1 ? cap1 : cap9;
+        // Too few tiles for the chip and a long K walk (the ConvTWA step: 58 tiles x 72 stages; the 12x20 / 23x40 maps of
+        // the backbone tail): K is split over up to 8 workgroups per tile, the shares meet in splitk_reduce_kernel
+        // (fixed order, no atomics).  The split is a function of the shape and of fixed constants only (512 workgroup
+        // slots = two per CU of a 256-CU part), not of the device the launch happens to run on.
+        k.ksplit = uavsal_f32_k32_ksplit(k.nblk, k.Kpad / 32);
+        if (k.ksplit > 1 && !(k.kpart && (k.epi == UAVSAL_EPI_AFFINE || k.epi == UAVSAL_EPI_TWA) &&
+                              (long long)k.ksplit * k.M * k.Npad * 4 <= k.kpart_bytes && !(k.Cout & 3) && !(k.ldc & 3) &&
+                              (k.epi != UAVSAL_EPI_TWA || (!(k.ldx & 3) && !(k.lda & 3) && !(k.ldr & 3)))))
+            k.ksplit = 1;
+        k.nblk *= k.ksplit;
         const int grid = k.nblk < cap ? k.nblk : cap;
-        hipLaunchKernelGGL((conv_gemm_f32_k32_kernel<WAVES_M, WAVES_N, 9, MINW>), dim3(grid), dim3(NT), SMEM, stream, k);
+        if (taps == 1)
+            hipLaunchKernelGGL((conv_gemm_f32_k32_kernel<WAVES_M, WAVES_N, 1, MINW>), dim3(grid), dim3(NT), SMEM, stream, k);
+        else
+            hipLaunchKernelGGL((conv_gemm_f32_k32_kernel<WAVES_M, WAVES_N, 9, MINW>), dim3(grid), dim3(NT), SMEM, stream, k);
+        if (k.ksplit > 1) return launch_splitk_reduce(k, 1.0f, stream);
     }
     return uavsal_launch_status();
 }
 
 }  // namespace
 
+// K shares per tile for `tiles` 128 x 128 tiles with `stages` 32-float K stages each (1: no split)
+__attribute__((visibility("hidden"))) int uavsal_f32_k32_ksplit(long long tiles, int stages) {
+    if (tiles <= 0 || tiles * 2 > 512) return 1;
+    int ksp = (int)(512 / tiles);
+    if (ksp > 8) ksp = 8;
+    while (ksp > 1 && stages / ksp < 6) --ksp;
+    return ksp;
+}
+
 __attribute__((visibility("hidden"))) bool uavsal_f32_k32_eligible(const uavsal_conv_desc* d, int tile) {
-    if (tile != 8 && tile != 9) return false;
+    if (tile < 8 || tile > 10) return false;
     if (d->prec != UAVSAL_PREC_F32 || d->dw_w9c || d->epi == UAVSAL_EPI_LSTM) return false;
     if ((d->Cin % 32) || d->Cin > UAVSAL_DWPROJ_MAX_C) return false;
+    if (tile == 10) {      // the flat-pipeline kernel only carries the vector affine epilogue
+        const bool vec = d->epi == UAVSAL_EPI_AFFINE && d->act != UAVSAL_ACT_SIGMOID && d->scale && d->bias &&
+                         !(d->ldc & 3) && !(d->Cout & 3) && uavsal_aligned16(d->out) &&
+                         (!d->res || (!(d->ldr & 3) && uavsal_aligned16(d->res)));
+        if (!vec) return false;
+    }
     return d->taps == 1 || d->taps == 9;
 }
 
 __attribute__((visibility("hidden"))) int uavsal_launch_f32_k32(const uavsal_gemm::ConvK& k, int taps, int tile,
                                                                  hipStream_t stream) {
+    if (tile == 10) return launch_k32<2, 2, 2, true>(k, taps, stream);    // 128 x 128, flat pipeline, 80 KB: two per CU
     if (tile == 9) return launch_k32<4, 2, 2>(k, taps, stream);     // 256 x 128 on 8 waves, one workgroup per CU
     return launch_k32<2, 2, 2>(k, taps, stream);                    // 128 x 128 on 4 waves, two per CU
 }

@@ -122,7 +122,7 @@ def conv_gemm(x, weight, scale=None, bias=None, act=L.ACT_NONE, res=None, out=No
     if split_in and not uses_split:
         raise RuntimeError("this shape / tile does not take the pre-split path")
     dwproj = int(lib.uavsal_conv_dwproj(C.byref(d))) != 0
-    k32 = prec == "f32" and int(lib.uavsal_conv_tile(C.byref(d))) in (8, 9)     # 32-float K stages: 3x3 K order differs
+    k32 = prec == "f32" and int(lib.uavsal_conv_tile(C.byref(d))) in (8, 9, 10)     # 32-float K stages: 3x3 K order differs
     wp = P.pack_conv_weight(weight, "f16x3i" if uses_split else ("f16x3j" if dwproj and prec == "f16x3" else
                                                                  ("f32k32" if k32 else prec))).to(x.device)
     keep.append(wp)
@@ -141,10 +141,9 @@ def twa_step(x_t, h_prev, pre_t, w_h, prec="f32", tile=0, stream_k=False):
     xp, ldr, *_ = _nhwc_view(x_t)
     pp, ldx, *_ = _nhwc_view(pre_t)
     out = torch.empty((n, h, w, c), dtype=torch.float32, device=x_t.device)
-    wp = P.pack_conv_weight(w_h, prec).to(x_t.device)
     d = L.ConvDesc()
     d.a, d.lda, d.a_img_stride = ap, lda, h * w
-    d.w = wp.data_ptr()
+    d.w = 1 << 20
     d.out, d.ldc, d.o_img_stride = out.data_ptr(), c, h * w
     d.res, d.ldr, d.r_img_stride = xp, ldr, h * w
     d.aux, d.ldx, d.x_img_stride = pp, ldx, h * w
@@ -153,6 +152,10 @@ def twa_step(x_t, h_prev, pre_t, w_h, prec="f32", tile=0, stream_k=False):
     if stream_k:
         ws = torch.zeros(int(lib.uavsal_streamk_workspace_bytes()), dtype=torch.uint8, device=x_t.device)
         d.sk_ws, d.sk_ws_bytes = ws.data_ptr(), ws.numel()
+    # weights last: the fp32 kernels with 32-float K stages (tiles 8-10) take the 3x3 K order in 32-channel blocks
+    k32 = prec == "f32" and int(lib.uavsal_conv_tile(C.byref(d))) in (8, 9, 10)
+    wp = P.pack_conv_weight(w_h, "f32k32" if k32 else prec).to(x_t.device)
+    d.w = wp.data_ptr()
     L.check(lib.uavsal_conv_gemm(C.byref(d), _stream(x_t)), "uavsal_conv_gemm(TWA)")
     torch.cuda.current_stream(x_t.device).synchronize()
     if stream_k:

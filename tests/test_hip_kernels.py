@@ -212,9 +212,71 @@ def test_twa_step_stream_k(ops):
     ref = gate * x + (1 - gate) * hp
     pre = ops.conv_gemm(nhwc(x), wt[:, :c].contiguous(), None, None, prec="f32")
     whole = ops.twa_step(nhwc(x), nhwc(hp), pre, wt[:, c:].contiguous(), prec="f32")
-    split = ops.twa_step(nhwc(x), nhwc(hp), pre, wt[:, c:].contiguous(), prec="f32", stream_k=True)
+    split = ops.twa_step(nhwc(x), nhwc(hp), pre, wt[:, c:].contiguous(), prec="f32", tile=4, stream_k=True)
     assert (split - whole).abs().max().item() <= TOL["f32"] * 4.0
     assert (nchw(split) - ref).abs().max().item() <= TOL["f32"] * 4.0
+
+
+@pytest.mark.parametrize("shape", [(1, 45, 80), (2, 12, 20), (1, 23, 40), (3, 9, 13)])
+def test_twa_step_f32_full_line_split_k(ops, shape):
+    """fp32 ConvTWA step on the kernel with 32-float K stages (tile 8) with K split over up to 8 workgroups per
+    128 x 128 tile (one clip at 45 x 80: 58 tiles x 72 stages -> 464 shares); the shares meet in the reduce launch, which
+    applies the ConvTWA update.  Against F.conv2d on the CPU, the whole-tile launch (tile 4) and its own second run."""
+    n, h, w = shape
+    c = 256
+    x = rnd((n, c, h, w), 50, 2.0)
+    hp = rnd((n, c, h, w), 51, 2.0)
+    wt = rnd((c, 2 * c, 3, 3), 52, 1.0 / np.sqrt(9 * 2 * c))
+    gate = torch.sigmoid(F.conv2d(torch.cat([x, hp], 1), wt, padding=1))
+    ref = gate * x + (1 - gate) * hp
+    pre = ops.conv_gemm(nhwc(x), wt[:, :c].contiguous(), None, None, prec="f32")
+    whole = ops.twa_step(nhwc(x), nhwc(hp), pre, wt[:, c:].contiguous(), prec="f32", tile=4)
+    split = ops.twa_step(nhwc(x), nhwc(hp), pre, wt[:, c:].contiguous(), prec="f32", tile=8, stream_k=True)
+    again = ops.twa_step(nhwc(x), nhwc(hp), pre, wt[:, c:].contiguous(), prec="f32", tile=8, stream_k=True)
+    assert torch.equal(split, again)                       # fixed summation order
+    assert (split - whole).abs().max().item() <= TOL["f32"] * 4.0
+    assert (nchw(split) - ref).abs().max().item() <= TOL["f32"] * 4.0
+
+
+@pytest.mark.parametrize("case", [(2, 12, 20, 1920, 256, 1, 1, True), (1, 23, 40, 960, 160, 1, 0, False),
+                                  (8, 12, 20, 1024, 256, 1, 1, False), (2, 12, 20, 256, 256, 9, 1, True)])
+def test_conv_f32_full_line_split_k(ops, case):
+    """Affine convs with few 128 x 128 tiles and a long K on tile 8 with the workspace: K split + reduce launch."""
+    n, h, w, cin, cout, taps, act, use_res = case
+    kk = 3 if taps == 9 else 1
+    x = rnd((n, cin, h, w), 53, 2.0)
+    wt = rnd((cout, cin, kk, kk), 54, 1.0 / np.sqrt(cin * taps))
+    scale = rnd((cout,), 55) * 0.5 + 1.0
+    bias = rnd((cout,), 56)
+    res = rnd((n, cout, h, w), 57) if use_res else None
+    ref = act_ref(F.conv2d(x, wt, padding=kk // 2) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1), act)
+    if use_res:
+        ref = ref + res
+    got = ops.conv_gemm(nhwc(x), wt, scale, bias, act=act, res=nhwc(res) if use_res else None, prec="f32", tile=8,
+                        stream_k=True)
+    assert (nchw(got) - ref).abs().max().item() <= TOL["f32"] * 4.0, case
+
+
+@pytest.mark.parametrize("tile", [8, 9, 10])
+@pytest.mark.parametrize("case", [(2, 12, 20, 256, 1536, 1, 1, False), (1, 23, 40, 1536, 256, 1, 0, True),
+                                  (3, 7, 5, 320, 256, 1, 1, False), (1, 45, 80, 32, 256, 1, 1, True),
+                                  (2, 13, 17, 96, 200, 1, 0, False), (1, 12, 20, 64, 96, 9, 1, False),
+                                  (2, 9, 13, 448, 256, 9, 1, False), (1, 45, 80, 256, 256, 9, 0, True)])
+def test_conv_f32_full_line_tiles(ops, tile, case):
+    """The fp32 kernels with 32-float (one cache line per row) K stages: 128 x 128 (8), 256 x 128 (9) and the flat
+    pipeline (10), 1x1 and 3x3 (weights packed with 32-channel K blocks), ragged M / N, residual."""
+    n, h, w, cin, cout, taps, act, use_res = case
+    kk = 3 if taps == 9 else 1
+    x = rnd((n, cin, h, w), 58, 2.0)
+    wt = rnd((cout, cin, kk, kk), 59, 1.0 / np.sqrt(cin * taps))
+    scale = rnd((cout,), 60) * 0.5 + 1.0
+    bias = rnd((cout,), 61)
+    res = rnd((n, cout, h, w), 62) if use_res else None
+    ref = act_ref(F.conv2d(x, wt, padding=kk // 2) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1), act)
+    if use_res:
+        ref = ref + res
+    got = ops.conv_gemm(nhwc(x), wt, scale, bias, act=act, res=nhwc(res) if use_res else None, prec="f32", tile=tile)
+    assert (nchw(got) - ref).abs().max().item() <= TOL["f32"] * 4.0, (tile, case)
 
 
 @pytest.mark.parametrize("prec", ["f16x3", "bf16x3"])

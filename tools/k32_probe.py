@@ -41,7 +41,7 @@ def parity():
             ref = ref + res
         xg = x.permute(0, 2, 3, 1).contiguous().cuda()
         rg = res.permute(0, 2, 3, 1).contiguous().cuda() if use_res else None
-        for tile in (1, 8, 9):
+        for tile in (1, 8, 9, 10):
             got = ops.conv_gemm(xg, wt, scale, bias, act=act, res=rg, prec="f32", tile=tile)
             err = (got.permute(0, 3, 1, 2).cpu() - ref).abs().max().item()
             ok = err <= 8e-5
@@ -52,11 +52,11 @@ def parity():
     return bad
 
 
-def run(hw, n_img, cin, cout, taps, tile, iters=20, launches_only=0):
+def run(hw, n_img, cin, cout, taps, tile, iters=20, launches_only=0, act=1, stamps=False):
     h, w = hw
     a = torch.rand((n_img * h * w, cin), device=dev) * 2 - 1
     wt = (torch.rand((cout, cin, 3 if taps == 9 else 1, 3 if taps == 9 else 1)) - 0.5) * 0.1
-    wp = P.pack_conv_weight(wt, "f32k32" if tile in (8, 9) else "f32").to(dev)
+    wp = P.pack_conv_weight(wt, "f32k32" if tile in (8, 9, 10) else "f32").to(dev)
     out = torch.empty((n_img * h * w, cout), device=dev)
     s = torch.ones(P.roundup(cout, 32), device=dev)
     b = torch.zeros(P.roundup(cout, 32), device=dev)
@@ -66,8 +66,19 @@ def run(hw, n_img, cin, cout, taps, tile, iters=20, launches_only=0):
     d.scale, d.bias = s.data_ptr(), b.data_ptr()
     d.out, d.ldc, d.o_img_stride = out.data_ptr(), cout, h * w
     d.n_img, d.H, d.W, d.Cin, d.Cout, d.taps = n_img, h, w, cin, cout, taps
-    d.prec, d.act, d.epi, d.tile = L.PREC["f32"], 1, 0, tile
+    d.prec, d.act, d.epi, d.tile = L.PREC["f32"], act, 0, tile
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    if stamps:      # libuavsal_hip_stamps.so: the kernel adds its cycle sums into the K-split area of the workspace
+        ws = torch.zeros(1 << 20, dtype=torch.uint8, device=dev)
+        d.sk_ws, d.sk_ws_bytes = ws.data_ptr(), ws.numel()
+        for _ in range(3):
+            L.check(lib.uavsal_conv_gemm(C.byref(d), st), "conv")
+        torch.cuda.synchronize()
+        ws.zero_()
+        L.check(lib.uavsal_conv_gemm(C.byref(d), st), "conv")
+        torch.cuda.synchronize()
+        v = ws[65536:65536 + 56].view(torch.int64).cpu().tolist()
+        return v
     if launches_only:
         for _ in range(launches_only):
             L.check(lib.uavsal_conv_gemm(C.byref(d), st), "conv")
@@ -92,14 +103,50 @@ SHAPES = [((45, 80), 8, 256, 1536, 1), ((45, 80), 8, 320, 1920, 1), ((45, 80), 8
 def timing():
     for sh in SHAPES:
         line = []
-        for tile in (1, 7, 8, 9):
+        for tile in (1, 7, 8, 9, 10):
             ms, tf = run(*sh, tile)
             line.append("t%d %7.1f us %6.1f TF" % (tile, ms * 1e3, tf))
         print("hw=%s n=%d K=%d N=%d taps=%d : %s" % (sh[0], sh[1], sh[2], sh[3], sh[4], " | ".join(line)), flush=True)
 
 
+def parts():
+    """UAVSAL_HIP_LIB=tools/_tmp/libuavsal_hip_probe.so: the kernel with parts compiled out."""
+    names = {1: "full", 101: "no store", 116: "no epilogue", 102: "no MFMA", 104: "no DMA", 108: "no frag reads",
+             106: "no MFMA, no DMA", 110: "no MFMA, no frag", 126: "K loop: DMA only", 124: "K loop: MFMA+frag only (no DMA, no epi)"}
+    for sh in (((45, 80), 8, 256, 1536, 1), ((45, 80), 64, 256, 1536, 1), ((45, 80), 8, 4096, 1536, 1)):
+        for tile in (8, 9, 10):
+            for act, nm in names.items():
+                ms, tf = run(*sh, tile, act=act)
+                print("parts n=%d K=%d N=%d tile=%d %-42s %8.1f us" % (sh[1], sh[2], sh[3], tile, nm, ms * 1e3), flush=True)
+
+
+def stamps():
+    """UAVSAL_HIP_LIB=tools/_tmp/libuavsal_hip_stamps.so: where the waves spend their cycles."""
+    for sh in (((45, 80), 8, 256, 1536, 1), ((45, 80), 64, 256, 1536, 1), ((45, 80), 8, 4096, 1536, 1), ((45, 80), 8, 448, 256, 9)):
+        for tile in (8, 10):
+            v = run(*sh, tile, stamps=True)
+            tot = max(v[4], 1)
+            if tile == 10:
+                print("stamps n=%d K=%d N=%d taps=%d tile=10 waves=%d: %.0f shader cycles per wave, in-kernel clock %.3f GHz" % (
+                    sh[1], sh[2], sh[3], sh[4], v[5], tot / max(v[5], 1), 0.1 * tot / max(v[6], 1)), flush=True)
+                continue
+            print("stamps n=%d K=%d N=%d taps=%d tile=%d waves=%d: wait %.1f%% body %.1f%% tail %.1f%% epilogue %.1f%% | per wave %.0f cycles" % (
+                sh[1], sh[2], sh[3], sh[4], tile, v[5], 100.0 * v[0] / tot, 100.0 * v[1] / tot, 100.0 * v[2] / tot,
+                100.0 * v[3] / tot, tot / max(v[5], 1)), flush=True)
+
+
 if __name__ == "__main__":
     mode = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if mode == "parts":
+        parts(); sys.exit(0)
+    if mode == "stamps":
+        stamps(); sys.exit(0)
+    if mode == "time8":      # tile 8 only, the shapes that matter (variant A/B through UAVSAL_HIP_LIB)
+        tl = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+        for sh in (SHAPES[0], SHAPES[1], SHAPES[5], SHAPES[6], SHAPES[7], SHAPES[9]):
+            ms, tf = run(*sh, tl)
+            print("n=%d K=%d N=%d taps=%d tile=%d: %8.1f us %6.1f TF" % (sh[1], sh[2], sh[3], sh[4], tl, ms * 1e3, tf), flush=True)
+        sys.exit(0)
     if mode == "pmc":
         tile = int(sys.argv[2])
         run((45, 80), 64, 256, 1536, 1, tile, launches_only=4)
