@@ -1790,6 +1790,8 @@ static int effective_tile(const uavsal_conv_desc* d) {
             const long long M = (long long)d->H * d->W * d->n_img;
             const int npad = (d->Cout + 31) / 32 * 32;
             const int ksp = uavsal_f32_k32_ksplit(((M + 127) / 128) * ((d->Cout + 127) / 128), d->taps * d->Cin / 32);
+            // (tile 10 reduces the shares inside the launch -- the last share to arrive adds them -- and measures 12 us
+            // SLOWER per ConvTWA step than shares + reduce launch: one workgroup per tile reads all the shares)
             if (ksp > 1 && (long long)ksp * M * npad * 4 <= d->sk_ws_bytes - 65536 && !(d->Cout & 3) && !(d->ldc & 3)) tile = 8;
         }
     }
@@ -1936,7 +1938,10 @@ extern "C" int uavsal_conv_gemm(const uavsal_conv_desc* d, uavsal_stream_t strea
             return t1 ? SkSmall::launch<1>(k, G, s) : SkSmall::launch<9>(k, G, s);
         }
     }
-    if (tile >= 8 && tile <= 10) return uavsal_launch_f32_k32(k, d->taps, tile, s);
+    if (tile >= 8 && tile <= 10) {
+        if (k.kpart) k.sk_flag = (int*)d->sk_ws;       // per-tile arrival counters of the K-split launch (zero between launches)
+        return uavsal_launch_f32_k32(k, d->taps, tile, s);
+    }
     switch (d->prec) {
         case UAVSAL_PREC_F32:    // the fused producer needs register staging: use the generic kernel
             return k.dw_w ? launch_prec<UAVSAL_PREC_F32>(k, d->taps, tile, s) : launch_f32(k, d->taps, tile, s);

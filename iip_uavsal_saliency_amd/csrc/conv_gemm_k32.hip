@@ -314,7 +314,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW) void conv_gemm_f32_k3
 //     flight and its first fragments are already in registers (the epilogue stages through its own 16 KB);
 //   * fragment reads are `ds_read_b128` in inline asm with counted `lgkmcnt` waits (hipcc re-merges the two fragment
 //     sets of a compiler-scheduled loop into one and waits `lgkmcnt(0)` in front of every sub-step).
-template <int WAVES_M, int WAVES_N, int TAPS, int MINW>
+// SPLIT: the launch's work units are (tile, K share) pairs, p.ksplit shares per tile (launches with few tiles and a
+// long K: the ConvTWA step).  A share publishes its raw sums (write-through stores), takes a ticket on the tile's
+// counter, and the share that arrives LAST adds all of them in share order -- the order is fixed, whoever reduces --
+// and applies the epilogue (BN / activation / residual or the ConvTWA update, model_convlstm.py:276-292).  Nobody waits.
+template <int WAVES_M, int WAVES_N, int TAPS, int MINW, bool SPLIT = false>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW) void conv_gemm_f32_k32p_kernel(const ConvK p) {
     constexpr int WM = 2, WN = 2;
     constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32;
@@ -350,7 +354,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW) void conv_gemm_f32_k3
 #ifdef UAVSAL_K32_STAMPS      // in-kernel clock: shader cycles (s_memtime) per 100 MHz tick (s_memrealtime) over the kernel
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime(), r_begin = __builtin_amdgcn_s_memrealtime();
 #endif
-    const int nst = p.Kpad / KT;
+    const int nst_all = p.Kpad / KT;
+    const int ksplit = SPLIT ? p.ksplit : 1;
 
     // ---- request side: the stream of stages (tile by tile) still to be requested
     const int r8 = tid >> 3;
@@ -359,10 +364,17 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW) void conv_gemm_f32_k3
     const float* b_ptr[B_IT];
     long long a_base[A_IT];
     int a_taps[A_IT];
-    int rq_tile = walk.tile, rq_kt = 0, it_tap = 0, it_cb = 0;
+    int rq_tile = walk.tile, rq_kt = 0, rq_nst = nst_all, it_tap = 0, it_cb = 0;
     long long tap_off = 0;
     int tap_bit = 0;
     auto setup_requests = [&](int t) {
+        int s0 = 0;
+        if (SPLIT) {                                     // work unit t = tile * ksplit + share
+            const int sh = t % ksplit;
+            t /= ksplit;
+            s0 = sh * nst_all / ksplit;
+            rq_nst = (sh + 1) * nst_all / ksplit - s0;
+        }
         const int tile_m = t / p.tiles_n;
         const int rm0 = tile_m * BM, rn0 = (t - tile_m * p.tiles_n) * BN;
 #pragma unroll
@@ -370,7 +382,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW) void conv_gemm_f32_k3
             const int m = rm0 + r8 + it * RPI;
             const bool ok = m < p.M;
             if (TAPS == 1) {
-                a_ptr[it] = ok ? p.a + row_off(m, p.HW, p.a_is, p.contig) * p.lda + lc * 4 : g_zero_row + lc * 4;
+                a_ptr[it] = (ok ? p.a + row_off(m, p.HW, p.a_is, p.contig) * p.lda + lc * 4 : g_zero_row + lc * 4) + s0 * KT;
             } else {
                 const int mm = ok ? m : 0;
                 const int img = mm / p.HW;
@@ -389,13 +401,13 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW) void conv_gemm_f32_k3
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
             const int nn = min(rn0 + r8 + it * RPI, p.Npad - 1);
-            b_ptr[it] = reinterpret_cast<const float*>(p.w) + (size_t)nn * p.Kpad + lc * 4;
+            b_ptr[it] = reinterpret_cast<const float*>(p.w) + (size_t)nn * p.Kpad + lc * 4 + s0 * KT;
         }
-        it_tap = 0; it_cb = 0;
+        it_cb = s0 / 9; it_tap = s0 - it_cb * 9;
     };
     // moves to the next stage of the stream; false when the stream is exhausted
     auto next_request = [&]() -> bool {
-        if (rq_kt == nst) {
+        if (rq_kt == rq_nst) {
             rq_tile += walk.stride;
             rq_kt = 0;
             if (rq_tile < walk.end) setup_requests(rq_tile);
@@ -478,7 +490,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW) void conv_gemm_f32_k3
     ldfrag(0, 0, 0);
 
     int g = 0;                                           // stages done so far: stage g lives in slot g & 1
-    for (int tile = walk.tile; tile < walk.end; tile += walk.stride) {
+    bool req = false;                                    // requests 2 .. LPT-1 of the stage announced at the last barrier are due
+    for (int unit = walk.tile; unit < walk.end; unit += walk.stride) {
+        const int tile = SPLIT ? unit / ksplit : unit, share = SPLIT ? unit - tile * ksplit : 0;
+        const int nst = SPLIT ? (share + 1) * nst_all / ksplit - share * nst_all / ksplit : nst_all;
         const int tile_m = tile / p.tiles_n;
         const int m0c = tile_m * BM, n0c = (tile - tile_m * p.tiles_n) * BN;
 #pragma unroll
@@ -487,17 +502,19 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW) void conv_gemm_f32_k3
             for (int j = 0; j < WN; ++j)
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
-        const bool last_tile = tile + walk.stride >= walk.end;
+        const bool last_tile = unit + walk.stride >= walk.end;
         float sc[WN], bi[WN];
 #pragma unroll
-        for (int j = 0; j < WN; ++j) {       // (scale / bias are padded to Npad; columns past it are never stored)
+        for (int j = 0; j < WN && !SPLIT; ++j) {       // (scale / bias are padded to Npad; columns past it are never stored)
             const int c = min(n0c + (wn * WN + j) * 32 + lr, p.Npad - 1);
             asm volatile("global_load_dword %0, %1, off" : "=v"(sc[j]) : "v"(p.scale + c) : "memory");
             asm volatile("global_load_dword %0, %1, off" : "=v"(bi[j]) : "v"(p.bias + c) : "memory");
         }
         for (int kt = 0; kt < nst; ++kt, ++g) {
             const int slot = g & 1;
-            // sub-steps 0..2: read the next sub-step's fragments, then multiply this one
+            // sub-steps 0..2: read the next sub-step's fragments, then multiply this one.  The requests of stage g + 1
+            // (announced behind the previous stage's barrier, into the other slot) go out ONE behind each MFMA group:
+            // a burst of them between two MFMAs stalls a wave that has its SIMD to itself for hundreds of cycles
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
                 ldfrag(slot, u + 1, (u + 1) & 1);
@@ -506,7 +523,14 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW) void conv_gemm_f32_k3
 #pragma unroll
                 for (int i = 0; i < WM; ++i)
 #pragma unroll
-                    for (int j = 0; j < WN; ++j) mma(u & 1, i, j);
+                    for (int j = 0; j < WN; ++j) {
+                        mma(u & 1, i, j);
+                        const int r = 2 + (u * WM + i) * WN + j;
+                        if (r < LPT) {
+                            if (req) issue_one(r, smem + (slot ^ 1) * STAGE);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
                 __builtin_amdgcn_sched_barrier(0);
             }
             // sub-step 3, first half
@@ -515,30 +539,116 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW) void conv_gemm_f32_k3
             mma(1, 0, 0);
             mma(1, 0, 1);
             __builtin_amdgcn_sched_barrier(0);
-            // the stage's one barrier: requests of stage g + 1 landed (a stage old), all fragments of stage g are in
-            // registers -> stage g + 1 is published and slot g & 1 is free
+            // the stage's one barrier: requests of stage g + 1 landed (most of a stage old), all fragments of stage g are
+            // in registers -> stage g + 1 is published and slot g & 1 is free
             asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
             const bool more = kt + 1 < nst || !last_tile;
             if (more) ldfrag(slot ^ 1, 0, 0);
-            const bool req = next_request();             // stage g + 2 -> slot g & 1
+            req = next_request();                        // stage g + 2 -> slot g & 1: first two requests here, the rest above
             __builtin_amdgcn_sched_barrier(0);
             mma(1, 1, 0);
-            if (req) {
-#pragma unroll
-                for (int r = 0; r < LPT / 2; ++r) issue_one(r, smem + slot * STAGE);
-            }
+            if (req) issue_one(0, smem + slot * STAGE);
+            __builtin_amdgcn_sched_barrier(0);
             mma(1, 1, 1);
-            if (req) {
-#pragma unroll
-                for (int r = LPT / 2; r < LPT; ++r) issue_one(r, smem + slot * STAGE);
-            }
+            if (req) issue_one(1, smem + slot * STAGE);
             __builtin_amdgcn_sched_barrier(0);
         }
         // ---- epilogue (folded BN, ReLU6 / none, optional residual), barrier-free: every wave passes its four
         // 32 x 32 accumulator blocks through its own 4 KB of LDS and stores them as 128-byte row segments.  The
         // BN scale / bias of the tile's columns were fetched at the tile's start by loads hipcc does not see (a
         // compiler-visible load left pending on some path makes it drain vmcnt(0) inside the K loop).
-        if (pr_epi) {
+        if constexpr (SPLIT) {
+            // (1) publish this share: raw sums -> p.kpart[share][M][Npad], device-coherent 16-byte stores
+            float* stg = reinterpret_cast<float*>(smem + 2 * STAGE) + wave_u * 1024;
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) stg[((q & 3) + 8 * (q >> 2) + 4 * lh) * 32 + lr] = acc[i][j][q];
+                    const int gn = n0c + (wn * WN + j) * 32 + (lane & 7) * 4;
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int row = (lane >> 3) + it * 8;
+                        const int gm = m0c + (wm * WM + i) * 32 + row;
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * 32 + (lane & 7) * 4);
+                        float* dst = p.kpart + ((size_t)share * p.M + gm) * p.Npad + gn;
+                        if (gm < p.M && gn < p.Npad)
+                            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(dst), "v"(v) : "memory");
+                    }
+                }
+            // (2) every wave's stores have left, then ONE ticket per share (MI355X_MICROARCH.md: inter-workgroup
+            // visibility, the counter form); the share that draws the last ticket reduces
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            int* ticket_lds = reinterpret_cast<int*>(smem + 2 * STAGE);
+            if (tid == 0) {
+                const int old = __hip_atomic_fetch_add(p.sk_flag + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int last = old == ksplit - 1;
+                if (last) {
+                    __hip_atomic_store(p.sk_flag + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                *ticket_lds = last;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            const bool reducer = *ticket_lds != 0;
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // (the word is staging space again)
+            if (reducer) {
+                // (3) shares in order 0 .. ksplit-1 (sc1 loads: served past this CU's L1), then the epilogue
+                const bool twa = p.epi == UAVSAL_EPI_TWA;
+                const float lo = p.act == UAVSAL_ACT_RELU6 ? 0.f : -3.0e38f;
+                const float hi = p.act == UAVSAL_ACT_RELU6 ? 6.f : 3.0e38f;
+                for (int it = 0; it < BM * BN / 4 / NT; it += 2) {
+                    f32x4 t[2][8];
+                    int gmv[2], gnv[2];
+                    bool okv[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int idx = tid + (it + e) * NT;
+                        const int row = idx / (BN / 4), c4 = idx - row * (BN / 4);
+                        gmv[e] = m0c + row; gnv[e] = n0c + c4 * 4;
+                        okv[e] = gmv[e] < p.M && gnv[e] < p.Cout;
+                        const float* src = p.kpart + ((size_t)(okv[e] ? gmv[e] : 0)) * p.Npad + (okv[e] ? gnv[e] : 0);
+#pragma unroll
+                        for (int sh = 0; sh < 8; ++sh)
+                            if (sh < ksplit)
+                                asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(t[e][sh])
+                                             : "v"(src + (size_t)sh * p.M * p.Npad) : "memory");
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)"
+                                 : "+v"(t[0][0]), "+v"(t[0][1]), "+v"(t[0][2]), "+v"(t[0][3]), "+v"(t[0][4]), "+v"(t[0][5]),
+                                   "+v"(t[0][6]), "+v"(t[0][7]), "+v"(t[1][0]), "+v"(t[1][1]), "+v"(t[1][2]), "+v"(t[1][3]),
+                                   "+v"(t[1][4]), "+v"(t[1][5]), "+v"(t[1][6]), "+v"(t[1][7]) :: "memory");
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        if (!okv[e]) continue;
+                        f32x4 v = t[e][0];
+#pragma unroll
+                        for (int sh = 1; sh < 8; ++sh)
+                            if (sh < ksplit) v += t[e][sh];
+                        const int gm = gmv[e], gn = gnv[e];
+                        const long long ro = row_off(gm, p.HW, p.o_is, p.contig);
+                        if (twa) {
+                            const f32x4 z = v + *reinterpret_cast<const f32x4*>(p.aux + row_off(gm, p.HW, p.x_is, p.contig) * p.ldx + gn);
+                            const f32x4 xt = *reinterpret_cast<const f32x4*>(p.res + row_off(gm, p.HW, p.r_is, p.contig) * p.ldr + gn);
+                            const f32x4 hp = *reinterpret_cast<const f32x4*>(p.a + row_off(gm, p.HW, p.a_is, p.contig) * p.lda + gn);
+                            f32x4 gt;
+                            gt.x = 1.f / (1.f + expf(-z.x)); gt.y = 1.f / (1.f + expf(-z.y));
+                            gt.z = 1.f / (1.f + expf(-z.z)); gt.w = 1.f / (1.f + expf(-z.w));
+                            v = gt * xt + (1.f - gt) * hp;
+                        } else {
+                            const f32x4 s4 = p.scale ? *reinterpret_cast<const f32x4*>(p.scale + gn) : (f32x4){1.f, 1.f, 1.f, 1.f};
+                            const f32x4 b4 = p.scale ? *reinterpret_cast<const f32x4*>(p.bias + gn) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                            v.x = __builtin_amdgcn_fmed3f(fmaf(v.x, s4.x, b4.x), lo, hi); v.y = __builtin_amdgcn_fmed3f(fmaf(v.y, s4.y, b4.y), lo, hi);
+                            v.z = __builtin_amdgcn_fmed3f(fmaf(v.z, s4.z, b4.z), lo, hi); v.w = __builtin_amdgcn_fmed3f(fmaf(v.w, s4.w, b4.w), lo, hi);
+                            if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + row_off(gm, p.HW, p.r_is, p.contig) * p.ldr + gn);
+                        }
+                        *reinterpret_cast<f32x4*>(p.out + ro * p.ldc + gn) = v;
+                    }
+                }
+            }
+        } else if (pr_epi) {
             float* stg = reinterpret_cast<float*>(smem + 2 * STAGE) + wave_u * 1024;
             const float lo = p.act == UAVSAL_ACT_RELU6 ? 0.f : -3.0e38f;
             const float hi = p.act == UAVSAL_ACT_RELU6 ? 6.f : 3.0e38f;
@@ -577,6 +687,16 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW) void conv_gemm_f32_k3
 #endif
 }
 
+// may this launch split K (workspace there and large enough for 8 shares, epilogue the reduce step carries, vector
+// alignment)?  -- the number of shares itself is uavsal_f32_k32_ksplit(tiles, stages)
+bool uavsal_f32_k32_split_ok(const ConvK& k) {
+    if (!k.kpart || !k.sk_flag || (k.epi != UAVSAL_EPI_AFFINE && k.epi != UAVSAL_EPI_TWA) || k.act == UAVSAL_ACT_SIGMOID) return false;
+    if (8LL * k.M * k.Npad * 4 > k.kpart_bytes || (k.Cout & 3) || (k.ldc & 3) || ((size_t)k.out & 15)) return false;
+    if (k.res && ((k.ldr & 3) || ((size_t)k.res & 15))) return false;
+    if (k.epi == UAVSAL_EPI_TWA && ((k.ldx & 3) || (k.lda & 3) || !k.res || !k.aux || ((size_t)k.aux & 15))) return false;
+    return true;
+}
+
 template <int WAVES_M, int WAVES_N, int MINW, bool FLAT = false>
 int launch_k32(const ConvK& k0, int taps, hipStream_t stream) {
     constexpr int BM = WAVES_M * 64, BN = WAVES_N * 64, NT = WAVES_M * WAVES_N * 64;
@@ -594,7 +714,18 @@ int launch_k32(const ConvK& k0, int taps, hipStream_t stream) {
         return per_cu * cus;
     };
     if constexpr (FLAT) {
-        if (taps == 1) {
+        k.ksplit = uavsal_f32_k32_split_ok(k) ? uavsal_f32_k32_ksplit(k.nblk, k.Kpad / 32) : 1;
+        if (k.ksplit > 1) {          // (tile, K share) work units, reduced in the launch by the last share to arrive
+            k.nblk *= k.ksplit;
+            static const int cap1 = cap_of(conv_gemm_f32_k32p_kernel<WAVES_M, WAVES_N, 1, MINW, true>);
+            static const int cap9 = cap_of(conv_gemm_f32_k32p_kernel<WAVES_M, WAVES_N, 9, MINW, true>);
+            const int cap = taps == 1 ? cap1 : cap9;
+            const int grid = k.nblk < cap ? k.nblk : cap;
+            if (taps == 1)
+                hipLaunchKernelGGL((conv_gemm_f32_k32p_kernel<WAVES_M, WAVES_N, 1, MINW, true>), dim3(grid), dim3(NT), SMEM, stream, k);
+            else
+                hipLaunchKernelGGL((conv_gemm_f32_k32p_kernel<WAVES_M, WAVES_N, 9, MINW, true>), dim3(grid), dim3(NT), SMEM, stream, k);
+        } else if (taps == 1) {
             static const int cap = cap_of(conv_gemm_f32_k32p_kernel<WAVES_M, WAVES_N, 1, MINW>);
             const int grid = k.nblk < cap ? k.nblk : cap;
             hipLaunchKernelGGL((conv_gemm_f32_k32p_kernel<WAVES_M, WAVES_N, 1, MINW>), dim3(grid), dim3(NT), SMEM, stream, k);
@@ -611,11 +742,7 @@ int launch_k32(const ConvK& k0, int taps, hipStream_t stream) {
         // the backbone tail): K is split over up to 8 workgroups per tile, the shares meet in splitk_reduce_kernel
         // (fixed order, no atomics).  The split is a function of the shape and of fixed constants only (512 workgroup
         // slots = two per CU of a 256-CU part), not of the device the launch happens to run on.
-        k.ksplit = uavsal_f32_k32_ksplit(k.nblk, k.Kpad / 32);
-        if (k.ksplit > 1 && !(k.kpart && (k.epi == UAVSAL_EPI_AFFINE || k.epi == UAVSAL_EPI_TWA) &&
-                              (long long)k.ksplit * k.M * k.Npad * 4 <= k.kpart_bytes && !(k.Cout & 3) && !(k.ldc & 3) &&
-                              (k.epi != UAVSAL_EPI_TWA || (!(k.ldx & 3) && !(k.lda & 3) && !(k.ldr & 3)))))
-            k.ksplit = 1;
+        k.ksplit = uavsal_f32_k32_split_ok(k) ? uavsal_f32_k32_ksplit(k.nblk, k.Kpad / 32) : 1;
         k.nblk *= k.ksplit;
         const int grid = k.nblk < cap ? k.nblk : cap;
         if (taps == 1)
@@ -632,8 +759,11 @@ int launch_k32(const ConvK& k0, int taps, hipStream_t stream) {
 // K shares per tile for `tiles` 128 x 128 tiles with `stages` 32-float K stages each (1: no split)
 __attribute__((visibility("hidden"))) int uavsal_f32_k32_ksplit(long long tiles, int stages) {
     if (tiles <= 0 || tiles * 2 > 512) return 1;
+    // measured on the ConvTWA step (58 tiles x 72 stages, one clip): 2 / 3 / 4 / 6 / 8 shares = 90 / 68 / 57 / 72 / 62 us
+    // (kernel + reduce launch), the 64 x 64 stream-K instance it replaces 65 -- profiles/r3_gemm_k32.md
+    static const int ksp_max = [] { const char* e = getenv("UAVSAL_K32_KSPLIT_MAX"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > 8 ? 8 : v); }();
     int ksp = (int)(512 / tiles);
-    if (ksp > 8) ksp = 8;
+    if (ksp > ksp_max) ksp = ksp_max;
     while (ksp > 1 && stages / ksp < 6) --ksp;
     return ksp;
 }
@@ -642,11 +772,20 @@ __attribute__((visibility("hidden"))) bool uavsal_f32_k32_eligible(const uavsal_
     if (tile < 8 || tile > 10) return false;
     if (d->prec != UAVSAL_PREC_F32 || d->dw_w9c || d->epi == UAVSAL_EPI_LSTM) return false;
     if ((d->Cin % 32) || d->Cin > UAVSAL_DWPROJ_MAX_C) return false;
-    if (tile == 10) {      // the flat-pipeline kernel only carries the vector affine epilogue
-        const bool vec = d->epi == UAVSAL_EPI_AFFINE && d->act != UAVSAL_ACT_SIGMOID && d->scale && d->bias &&
-                         !(d->ldc & 3) && !(d->Cout & 3) && uavsal_aligned16(d->out) &&
-                         (!d->res || (!(d->ldr & 3) && uavsal_aligned16(d->res)));
-        if (!vec) return false;
+    if (tile == 10) {      // the flat-pipeline kernel carries the vector affine epilogue; with K split (few tiles, long K,
+                           // workspace given) the reducing share also does the ConvTWA update
+        const bool al = d->act != UAVSAL_ACT_SIGMOID && !(d->ldc & 3) && !(d->Cout & 3) && uavsal_aligned16(d->out) &&
+                        (!d->res || (!(d->ldr & 3) && uavsal_aligned16(d->res)));
+        const long long M = (long long)d->H * d->W * d->n_img;
+        const int npad = (d->Cout + 31) / 32 * 32;
+        const bool split = d->sk_ws && uavsal_aligned16(d->sk_ws) && d->sk_ws_bytes - 65536 >= 8LL * M * npad * 4 &&
+                           uavsal_f32_k32_ksplit(((M + 127) / 128) * ((d->Cout + 127) / 128), d->taps * d->Cin / 32) > 1;
+        if (split) {
+            if (!al || (d->epi != UAVSAL_EPI_AFFINE && d->epi != UAVSAL_EPI_TWA)) return false;
+            if (d->epi == UAVSAL_EPI_TWA && ((d->ldx & 3) || (d->lda & 3) || !d->res || !d->aux || !uavsal_aligned16(d->aux))) return false;
+        } else if (!(al && d->epi == UAVSAL_EPI_AFFINE && d->scale && d->bias)) {
+            return false;
+        }
     }
     return d->taps == 1 || d->taps == 9;
 }

@@ -14,6 +14,7 @@ stream.  PyTorch is used for device memory and streams, not for arithmetic.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -653,8 +654,12 @@ class Engine:
             r = self._buf("st%d_red" % i, N, h, w, 32)
             dif = self._buf("st%d_dif" % i, N, h, w, 64)
             t1 = self._buf("st%d_te1" % i, N, h, w, 32)
-            # temporal branch (small launches) on lane 6, next to the spatial branch's big GEMMs
-            self.fork(6)
+            # temporal branch (small launches): st_lanes 1 = all of it on lane 6, next to the spatial branch's big GEMMs;
+            # 2 = its first two launches on the main lane (they would otherwise queue behind a grid-filling GEMM for
+            # the whole of it), the rest on lane 6; 0 = no side lane
+            st_lanes = int(os.environ.get("UAVSAL_ST_LANES", "2"))     # (same box, two runs each: 5.26 / 5.25 / 5.22 ms for 1 / 0 / 2)
+            if st_lanes == 1:
+                self.fork(6)
             self.conv("st%d.reduce" % i, x, te.reduce_conv[0], te.reduce_conv[1], r, R6)
             self._meta(kind="tdiff", name="st%d.tdiff" % i, flops=0.0, bytes=4.0 * N * hw * 96)
             if not self._dry:
@@ -662,10 +667,14 @@ class Engine:
                 d.inp, d.ldi, d.out, d.ldo = r.ptr, 32, dif.ptr, 64
                 d.n_img, d.HW, d.C, d.seq_len = N, hw, 32, self.seq_len
                 self._add(self.lib.uavsal_plan_add_tdiff, d, "plan_add_tdiff")
+            if st_lanes == 2:
+                self.fork(6)
             self.ir_block("st%d.sub" % i, dif, te.sub_conv, t1)
-            self.main()
+            if st_lanes:
+                self.main()
             self.ir_block("st%d.sp" % i, x, st.stconv_sp.spconv, sp)
-            self.join(6)
+            if st_lanes:
+                self.join(6)
             ssum = self._buf("st%d_sum" % i, N, h, w, 256)
             self.conv("st%d.te_last" % i, t1, te.last_conv[0], te.last_conv[1], ssum, R6, res=sp)   # x_sp + x_te
             y = self._buf("st%d" % i, N, h, w, 256)

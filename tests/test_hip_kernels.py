@@ -231,11 +231,12 @@ def test_twa_step_f32_full_line_split_k(ops, shape):
     ref = gate * x + (1 - gate) * hp
     pre = ops.conv_gemm(nhwc(x), wt[:, :c].contiguous(), None, None, prec="f32")
     whole = ops.twa_step(nhwc(x), nhwc(hp), pre, wt[:, c:].contiguous(), prec="f32", tile=4)
-    split = ops.twa_step(nhwc(x), nhwc(hp), pre, wt[:, c:].contiguous(), prec="f32", tile=8, stream_k=True)
-    again = ops.twa_step(nhwc(x), nhwc(hp), pre, wt[:, c:].contiguous(), prec="f32", tile=8, stream_k=True)
-    assert torch.equal(split, again)                       # fixed summation order
-    assert (split - whole).abs().max().item() <= TOL["f32"] * 4.0
-    assert (nchw(split) - ref).abs().max().item() <= TOL["f32"] * 4.0
+    for tile in (8, 10, 0):     # 8: shares + reduce launch; 10: flat pipeline, the last share to arrive reduces; 0: the default
+        split = ops.twa_step(nhwc(x), nhwc(hp), pre, wt[:, c:].contiguous(), prec="f32", tile=tile, stream_k=True)
+        again = ops.twa_step(nhwc(x), nhwc(hp), pre, wt[:, c:].contiguous(), prec="f32", tile=tile, stream_k=True)
+        assert torch.equal(split, again), tile                       # fixed summation order, whoever reduces
+        assert (split - whole).abs().max().item() <= TOL["f32"] * 4.0, tile
+        assert (nchw(split) - ref).abs().max().item() <= TOL["f32"] * 4.0, tile
 
 
 @pytest.mark.parametrize("case", [(2, 12, 20, 1920, 256, 1, 1, True), (1, 23, 40, 960, 160, 1, 0, False),
@@ -252,9 +253,10 @@ def test_conv_f32_full_line_split_k(ops, case):
     ref = act_ref(F.conv2d(x, wt, padding=kk // 2) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1), act)
     if use_res:
         ref = ref + res
-    got = ops.conv_gemm(nhwc(x), wt, scale, bias, act=act, res=nhwc(res) if use_res else None, prec="f32", tile=8,
-                        stream_k=True)
-    assert (nchw(got) - ref).abs().max().item() <= TOL["f32"] * 4.0, case
+    for tile in (8, 10):
+        got = ops.conv_gemm(nhwc(x), wt, scale, bias, act=act, res=nhwc(res) if use_res else None, prec="f32", tile=tile,
+                            stream_k=True)
+        assert (nchw(got) - ref).abs().max().item() <= TOL["f32"] * 4.0, (tile, case)
 
 
 @pytest.mark.parametrize("tile", [8, 9, 10])
