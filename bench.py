@@ -60,33 +60,54 @@ def kernel_symbol(prec, tile, taps, streamk=0, split=False):
     return "conv_gemm_kernel<%s>" % (H16_INST[tile] % (PREC_ID[prec], taps))
 
 
-TRAFFIC_FILE = os.path.join("profiles", "r2_hbm_traffic_f32_c1.json")
+def traffic_file(C, prec):
+    return os.path.join("profiles", "r3_hbm_traffic_%s_c%d.json" % (prec, C))
+
+
+def inloop_file(C, prec):
+    return os.path.join("profiles", "r3_kernel_stats_%s_c%d.json" % (prec, C))
+
+
+def _stamped(path, T, H, W):
+    """A committed profile summary, or (None, why): it must exist, be for 8-frame 360x640 clips and carry the hash of
+    the kernel sources of THIS build."""
+    full = os.path.join(ROOT, path)
+    if (T, H, W) != (8, 360, 640) or not os.path.exists(full):
+        return None, "no collection for this workload"
+    blob = json.load(open(full))
+    if blob.get("__stamp__", {}).get("kernel_sources_sha16") != kernel_sources_sha16():
+        return None, "stale: kernel sources changed since the collection"
+    return blob, "ok"
 
 
 def measured_traffic(symbol, C, T, H, W, prec):
     """(HBM bytes per launch, source) from the committed rocprofv3 PMC passes: two separate `--pmc` runs of
     this bench command (FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md, + WRITE_SIZE),
     summarised by tools/traffic_report.py.  The counters cannot be collected by the run that prints the
-    line (rocprofv3 wraps the process), so the file carries a stamp -- ABI version and a hash of the kernel
-    sources it was collected on -- and the figure is withheld (null) when the stamp does not match this
-    build or the workload is not the one it was collected for."""
-    src = {"file": TRAFFIC_FILE, "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), FETCH x2 (gfx950)"}
-    path = os.path.join(ROOT, TRAFFIC_FILE)
-    if (C, T, H, W, prec) != (1, 8, 360, 640, "f32") or not os.path.exists(path):
-        src["status"] = "no PMC collection for this workload"
+    line (rocprofv3 wraps the process), so the file carries a stamp -- a hash of the kernel sources it was
+    collected on -- and the figure is withheld (null) when the stamp does not match this build or there is no
+    collection for the workload (tools/collect_profiles.sh: 1 and 8 clips in f32, 8 clips in f16x3)."""
+    src = {"file": traffic_file(C, prec), "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), FETCH x2 (gfx950)"}
+    blob, why = _stamped(src["file"], T, H, W)
+    src["status"] = why
+    if blob is None:
         return None, src
-    blob = json.load(open(path))
-    stamp = blob.get("__stamp__", {})
-    src["stamp"] = stamp
-    if stamp.get("kernel_sources_sha16") != kernel_sources_sha16():
-        src["status"] = "stale: kernel sources changed since the PMC passes"
-        return None, src
+    src["stamp"] = blob.get("__stamp__", {})
     rec = blob.get(symbol)
     if rec is None:
         src["status"] = "kernel not in the PMC summary"
         return None, src
-    src["status"] = "ok"
     return round(rec["hbm_mb_per_launch"] * 1e6), src
+
+
+def in_loop_timing(symbol, C, T, H, W, prec):
+    """Average duration of the kernel instance INSIDE the timed loop (rocprofv3 --kernel-trace --stats of this bench
+    command, tools/kernel_stats_report.py): lanes overlap there and kernels queue behind each other, so it differs from
+    the isolated per-op hipEvent timing the `roofline` objects are computed from."""
+    blob, why = _stamped(inloop_file(C, prec), T, H, W)
+    if blob is None or symbol not in blob:
+        return {"status": why if blob is None else "kernel not in the summary", "file": inloop_file(C, prec)}
+    return {"status": "ok", "file": inloop_file(C, prec), "avg_launch_us": blob[symbol]["avg_us"], "calls": blob[symbol]["calls"]}
 
 
 def kernel_sources_sha16():
@@ -367,6 +388,15 @@ def main():
             result["roofline"] = roofline_obj(dom[0], dom[1], args.prec)
             result["roofline"]["share_of_kernel_time"] = round(dom[1]["ms"] / tot, 3)
             result["roofline"]["traffic"], result["roofline"]["traffic_source"] = measured_traffic(dom[0], C, T, H, W, args.prec)
+            result["roofline"]["timing"] = "isolated: hipEvents around each op of the plan on the launch stream, 5 back-to-back repeats"
+            il = in_loop_timing(dom[0], C, T, H, W, args.prec)
+            if il.get("status") == "ok":       # the same launches inside the overlapped timed loop (rocprofv3 average)
+                per_launch = dom[1]["flops"] / dom[1]["launches"]
+                il["achieved"] = round(per_launch / (il["avg_launch_us"] * 1e-6) / 1e12, 2)
+                il["frac"] = round(il["achieved"] / PEAK_TFLOPS[args.prec], 4)
+            result["roofline"]["in_loop"] = il
+            result["roofline"]["clock_note"] = ("peak is the 2.4 GHz figure; under these GEMMs the chip holds 2.0-2.15 GHz "
+                                                "(in-kernel s_memtime / s_memrealtime, profiles/r3_gemm_k32.md)")
             fam = depthwise_family(groups)
             if fam:
                 fam["share_of_kernel_time"] = round(fam["kernel_ms_per_step"] / tot, 3)

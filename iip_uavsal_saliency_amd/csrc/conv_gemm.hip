@@ -1797,7 +1797,9 @@ static int effective_tile(const uavsal_conv_desc* d) {
     }
     if (d->tile == 0 && tile == 1 && d->prec == UAVSAL_PREC_F32) {
         static const int k32_mode = [] { const char* e = getenv("UAVSAL_K32"); return e ? atoi(e) : 1; }();
-        if (k32_mode && uavsal_f32_k32_eligible(d, 8) && d->epi == UAVSAL_EPI_AFFINE &&
+        // (K of at least four 32-float stages: at K = 64 the 16-float instance is 1-2 us faster per launch -- three ring
+        // stages against two -- and at K = 32 the launch is store-bound either way)
+        if (k32_mode && uavsal_f32_k32_eligible(d, 8) && d->epi == UAVSAL_EPI_AFFINE && d->taps * d->Cin >= 128 &&
             streamk_plan(d, 1, (d->taps * d->Cin + 15) / 16) == 0) {
             const long long M = (long long)d->H * d->W * d->n_img;
             tile = (k32_mode == 9 && d->Cout % 128 == 0 && ((M + 255) / 256) * (d->Cout / 128) >= 1024) ? 9 : 8;

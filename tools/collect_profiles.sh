@@ -1,18 +1,30 @@
-# How the profiles/r2_* set was produced on the GPU box (run through gpurun from the repo root, then copy
-# gpurun_out/r2final/{kt/kt_kernel_stats.csv, r2_hbm_traffic_f32_c1.json, traffic.txt, bench_*.json/.err} into profiles/).
+# How the profiles/r3_* set is produced on the GPU box (run through gpurun from the repo root; afterwards copy
+# gpurun_out/r3final/* into profiles/).  Per workload: rocprofv3 --kernel-trace --stats, two PMC passes (FETCH_SIZE,
+# WRITE_SIZE: separate runs, no tracing), the summaries bench.py quotes (stamped with the kernel-source hash), and the
+# bench line itself.  The program goes directly after `--`.
 set -e
 R=$GRAFT_REPO_ROOT
-cd /tmp && export TMPDIR=/tmp
-rm -rf $R/gpurun_out/r2final && mkdir -p $R/gpurun_out/r2final
-rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/r2final/f -o f --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-extra --no-roofline --steps 5 --windows 1 > /dev/null 2> $R/gpurun_out/r2final/f.err
-rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/r2final/w -o w --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-extra --no-roofline --steps 5 --windows 1 > /dev/null 2> $R/gpurun_out/r2final/w.err
+O=$R/gpurun_out/r3final
+rm -rf $O && mkdir -p $O
+run_set() {   # $1 = prec, $2 = clips, $3 = label
+  local P=$1 C=$2 L="$3" T=${1}_c${2}
+  cd /tmp && export TMPDIR=/tmp
+  rocprofv3 --pmc FETCH_SIZE -d $O/f_$T -o f --output-format csv -- python3 $R/bench.py --prec $P --clips $C --no-cpu-baseline --no-extra --no-roofline --steps 5 --windows 1 > /dev/null 2> $O/f_$T.err
+  rocprofv3 --pmc WRITE_SIZE -d $O/w_$T -o w --output-format csv -- python3 $R/bench.py --prec $P --clips $C --no-cpu-baseline --no-extra --no-roofline --steps 5 --windows 1 > /dev/null 2> $O/w_$T.err
+  rocprofv3 --kernel-trace --stats -d $O/kt_$T -o kt --output-format csv -- python3 $R/bench.py --prec $P --clips $C --no-cpu-baseline --no-extra --no-roofline > $O/kt_bench_$T.json 2> $O/kt_$T.err
+  cd $R
+  python3 tools/traffic_report.py $O/f_$T/f_counter_collection.csv $O/w_$T/w_counter_collection.csv $O/r3_hbm_traffic_$T.json "$L" > $O/r3_hbm_traffic_$T.txt
+  python3 tools/kernel_stats_report.py $O/kt_$T/kt_kernel_stats.csv $O/r3_kernel_stats_$T.json "$L" > $O/r3_kernel_stats_$T.txt
+  cp $O/kt_$T/kt_kernel_stats.csv $O/r3_bench_${T}_kernel_stats.csv
+  cp $O/r3_hbm_traffic_$T.json $O/r3_kernel_stats_$T.json profiles/     # so that the bench line below can quote them
+  rm -rf $O/f_$T $O/w_$T $O/kt_$T/kt_kernel_trace.csv
+}
+run_set f32 1 "bench.py (configs[1]: 360x640, 1 clip x 8 frames, f32)"
+run_set f32 8 "bench.py --clips 8 (one GPU's share of configs[3]: 360x640, 8 clips x 8 frames, f32)"
+run_set f16x3 8 "bench.py --prec f16x3 --clips 8 (configs[2]: 360x640, 8 clips x 8 frames, split-fp16 MFMA)"
 cd $R
-python3 tools/traffic_report.py gpurun_out/r2final/f/f_counter_collection.csv gpurun_out/r2final/w/w_counter_collection.csv profiles/r2_hbm_traffic_f32_c1.json > gpurun_out/r2final/traffic.txt
-cp profiles/r2_hbm_traffic_f32_c1.json gpurun_out/r2final/
-cd /tmp
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/r2final/kt -o kt --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-extra > $R/gpurun_out/r2final/kt_bench.json 2> $R/gpurun_out/r2final/kt.err
-cd $R
-python3 bench.py > gpurun_out/r2final/bench_default.json 2> gpurun_out/r2final/bench_default.err
-python3 bench.py --prec f16x3 --no-extra --no-cpu-baseline > gpurun_out/r2final/bench_f16x3_c1.json 2> gpurun_out/r2final/bench_f16x3_c1.err
-python3 bench.py --prec f16x3 --clips 8 --no-extra --no-cpu-baseline > gpurun_out/r2final/bench_f16x3_c8.json 2> gpurun_out/r2final/bench_f16x3_c8.err
-python3 bench.py --clips 8 --no-extra --no-cpu-baseline > gpurun_out/r2final/bench_f32_c8.json 2> gpurun_out/r2final/bench_f32_c8.err
+python3 bench.py > $O/r3_bench_default.json 2> $O/r3_bench_default.err
+python3 bench.py --clips 8 --no-extra --no-cpu-baseline > $O/r3_bench_f32_c8.json 2> $O/r3_bench_f32_c8.err
+python3 bench.py --prec f16x3 --clips 8 --no-extra --no-cpu-baseline > $O/r3_bench_f16x3_c8.json 2> $O/r3_bench_f16x3_c8.err
+python3 bench.py --prec f16x3 --no-extra --no-cpu-baseline > $O/r3_bench_f16x3_c1.json 2> $O/r3_bench_f16x3_c1.err
+ls $O

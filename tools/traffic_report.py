@@ -10,7 +10,7 @@ def load(path, counter):
         if r["Counter_Name"] != counter:
             continue
         k = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
-        k = re.sub(r"\(ConvK\)|\(DwK\)|\(.*\)$", "", k).replace("void ", "").strip()
+        k = re.sub(r"\((uavsal_gemm::)?ConvK\)|\(DwK\)|\(.*\)$", "", k).replace("void ", "").strip()
         agg[k][0] += float(r["Counter_Value"])
         agg[k][1] += 1
     return agg
@@ -35,7 +35,8 @@ for name in sorted(os.listdir(base)):
         h.update(name.encode())
         h.update(open(os.path.join(base, name), "rb").read())
 h.update(open(os.path.join(ROOT, "include", "uavsal_hip.h"), "rb").read())
-out["__stamp__"] = {"kernel_sources_sha16": h.hexdigest()[:16], "workload": "python3 bench.py --no-cpu-baseline --no-extra (configs[1]: 360x640, 1 clip x 8 frames, f32)",
+out["__stamp__"] = {"kernel_sources_sha16": h.hexdigest()[:16],
+                    "workload": sys.argv[4] if len(sys.argv) > 4 else "python3 bench.py --no-cpu-baseline --no-extra (configs[1]: 360x640, 1 clip x 8 frames, f32)",
                     "collected": datetime.date.today().isoformat()}
 json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
 for k, v in out.items():
