@@ -1773,8 +1773,9 @@ int pick_tile(long long M, int Cout, int prec) {
 }  // namespace
 
 static int effective_tile(const uavsal_conv_desc* d) {
-    int tile = (d->tile >= 1 && d->tile <= 10) ? d->tile
+    int tile = (d->tile >= 1 && d->tile <= 11) ? d->tile
                                              : pick_tile((long long)d->H * d->W * d->n_img, d->Cout, d->prec);
+    if (tile == 11 && !uavsal_f32_k32_eligible(d, tile)) tile = 4;
     if (tile == 10 && !uavsal_f32_k32_eligible(d, 10)) tile = 8;
     if ((tile == 8 || tile == 9) && !uavsal_f32_k32_eligible(d, tile)) tile = tile == 9 ? 7 : 1;   // full-line K stages
     // automatic choice: the 128 x 128 launches that do not take the stream-K path move to the kernel with 32-float K
@@ -1794,6 +1795,18 @@ static int effective_tile(const uavsal_conv_desc* d) {
             // SLOWER per ConvTWA step than shares + reduce launch: one workgroup per tile reads all the shares)
             if (ksp > 1 && (long long)ksp * M * npad * 4 <= d->sk_ws_bytes - 65536 && !(d->Cout & 3) && !(d->ldc & 3)) tile = 8;
         }
+    }
+    // ... and affine convs on the small backbone maps with a long K (the 12x20 projections: at most 160 tiles of 64 x 64,
+    // at least 24 stages) take the 64 x 64 instance with K shares over workgroups reduced inside the launch (tile 11):
+    // 17.0 / 23.2 / 26.9 / 18.1 us against 19.5 / 26.6 / 32.7 / 25.2 for the stream-K instance (profiles/r3_gemm_k32.md)
+    if (d->tile == 0 && tile == 4 && d->prec == UAVSAL_PREC_F32 && d->epi == UAVSAL_EPI_AFFINE && d->sk_ws && d->sk_ws_bytes > 65536) {
+        static const int k32_mode = [] { const char* e = getenv("UAVSAL_K32"); return e ? atoi(e) : 1; }();
+        static const int small_mode = [] { const char* e = getenv("UAVSAL_K32_SMALL"); return e ? atoi(e) : 1; }();
+        const long long M = (long long)d->H * d->W * d->n_img;
+        const long long tiles64 = ((M + 63) / 64) * ((d->Cout + 63) / 64);
+        if (k32_mode && small_mode && tiles64 <= 160 && d->taps * d->Cin / 32 >= 24 && uavsal_f32_k32_eligible(d, 11) &&
+            d->act != UAVSAL_ACT_SIGMOID && !(d->Cout & 3) && !(d->ldc & 3))
+            tile = 11;
     }
     if (d->tile == 0 && tile == 1 && d->prec == UAVSAL_PREC_F32) {
         static const int k32_mode = [] { const char* e = getenv("UAVSAL_K32"); return e ? atoi(e) : 1; }();
@@ -1940,7 +1953,7 @@ extern "C" int uavsal_conv_gemm(const uavsal_conv_desc* d, uavsal_stream_t strea
             return t1 ? SkSmall::launch<1>(k, G, s) : SkSmall::launch<9>(k, G, s);
         }
     }
-    if (tile >= 8 && tile <= 10) {
+    if (tile >= 8 && tile <= 11) {
         if (k.kpart) k.sk_flag = (int*)d->sk_ws;       // per-tile arrival counters of the K-split launch (zero between launches)
         return uavsal_launch_f32_k32(k, d->taps, tile, s);
     }

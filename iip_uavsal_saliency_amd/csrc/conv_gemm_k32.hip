@@ -611,10 +611,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW) void conv_gemm_f32_k3
                         okv[e] = gmv[e] < p.M && gnv[e] < p.Cout;
                         const float* src = p.kpart + ((size_t)(okv[e] ? gmv[e] : 0)) * p.Npad + (okv[e] ? gnv[e] : 0);
 #pragma unroll
-                        for (int sh = 0; sh < 8; ++sh)
-                            if (sh < ksplit)
-                                asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(t[e][sh])
-                                             : "v"(src + (size_t)sh * p.M * p.Npad) : "memory");
+                        for (int sh = 0; sh < 8; ++sh) {     // (no branch around a load; absent shares re-read share 0)
+                            const int she = sh < ksplit ? sh : 0;
+                            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(t[e][sh])
+                                         : "v"(src + (size_t)she * p.M * p.Npad) : "memory");
+                        }
                     }
                     asm volatile("s_waitcnt vmcnt(0)"
                                  : "+v"(t[0][0]), "+v"(t[0][1]), "+v"(t[0][2]), "+v"(t[0][3]), "+v"(t[0][4]), "+v"(t[0][5]),
@@ -685,6 +686,213 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW) void conv_gemm_f32_k3
         atomicAdd(dbg + 6, __builtin_amdgcn_s_memrealtime() - r_begin);
     }
 #endif
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Few tiles, long K (the ConvTWA step: 3600 rows x 256 columns x K 2304; the projections of the 12x20 / 23x40 backbone
+// maps).  What bounds such a launch is the matrix work of ONE tile on ONE CU (a 64 x 64 x 960 tile is 30 700 cycles
+// of its CU's four matrix pipes whatever the workgroup looks like: splitting K over wave groups INSIDE a workgroup
+// was built and measured -- 22.3 against 23.4 us -- and dropped), so the tile's K range is split over several
+// workgroups = several CUs:  64 x 64 tiles, four waves, two-stage ring (32 KB: several workgroups per CU), work units
+// (tile, K share).  A share publishes its 16 KB of raw sums (write-through stores) and takes a ticket on the tile's
+// counter; the share that draws the last ticket adds all of them in share order -- one round of loads, 64 KB -- and
+// applies the epilogue (BN / activation / residual, or the ConvTWA update).  Nobody waits, the order is fixed.
+// SPLIT = false is the plain 64 x 64 instance (the usual epilogue, any epilogue kind).
+template <int TAPS, bool SPLIT>
+__global__ __launch_bounds__(256, 3) void conv_gemm_f32_k32s_kernel(const ConvK p) {
+    constexpr int WM = 1, WN = 1, WAVES_N = 2;
+    constexpr int BM = 64, BN = 64, KT = 32, NT = 256;
+    constexpr int APAN = BM * 128, BPAN = BN * 128, STAGE = APAN + BPAN;
+    constexpr int MAXS = 4;                              // K shares per tile at most
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+
+    const int tid = threadIdx.x;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int wm = wave_u / WAVES_N, wn = wave_u - wm * WAVES_N;
+    const int lr = lane & 31, lh = lane >> 5;
+    const uavsal_tile_walk walk = xcd_tile_walk(blockIdx.x, gridDim.x, p.nblk);
+    int unit = walk.tile;
+    if (unit >= walk.end) return;
+
+    const int nst_all = p.Kpad / KT;
+    const int ksplit = SPLIT ? p.ksplit : 1;
+    int m0 = 0, n0 = 0, nst = nst_all, tile_id = 0, share = 0;
+    const int r8 = tid >> 3;
+    const int lc = (tid & 7) ^ ((r8 >> 1) & 7);
+    const float* a_ptr[2];
+    const float* b_ptr[2];
+    long long a_base[2];
+    int a_taps[2];
+    int it_tap = 0, it_cb = 0;
+    long long tap_off = 0;
+    int tap_bit = 0;
+    auto setup_unit = [&](int u) {
+        int s0 = 0;
+        tile_id = u;
+        if (SPLIT) {                                     // work unit = tile * ksplit + share
+            share = u % ksplit;
+            tile_id = u / ksplit;
+            s0 = share * nst_all / ksplit;
+            nst = (share + 1) * nst_all / ksplit - s0;
+        }
+        const int tile_m = tile_id / p.tiles_n;
+        m0 = tile_m * BM;
+        n0 = (tile_id - tile_m * p.tiles_n) * BN;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int m = m0 + r8 + it * 32;
+            const bool ok = m < p.M;
+            if (TAPS == 1) {
+                a_ptr[it] = (ok ? p.a + row_off(m, p.HW, p.a_is, p.contig) * p.lda + lc * 4 : g_zero_row + lc * 4) + s0 * KT;
+            } else {
+                const int mm = ok ? m : 0;
+                const int img = mm / p.HW;
+                const int pix = mm - img * p.HW;
+                const int y = pix / p.W, x = pix - y * p.W;
+                a_base[it] = ((long long)img * p.a_is + pix) * p.lda + lc * 4;
+                int mask = 0;
+#pragma unroll
+                for (int tp = 0; tp < 9; ++tp) {
+                    const int yy = y + tp / 3 - 1, xx = x + tp % 3 - 1;
+                    if (ok && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) mask |= 1 << tp;
+                }
+                a_taps[it] = mask;
+            }
+            const int nn = min(n0 + r8 + it * 32, p.Npad - 1);
+            b_ptr[it] = reinterpret_cast<const float*>(p.w) + (size_t)nn * p.Kpad + lc * 4 + s0 * KT;
+        }
+        it_cb = s0 / 9; it_tap = s0 - it_cb * 9;
+    };
+    auto issue_stage = [&](char* st) {
+        if (TAPS == 9) {
+            const int ty = (it_tap * 11) >> 5;
+            tap_off = (long long)((ty - 1) * p.W + (it_tap - ty * 3 - 1)) * p.lda + it_cb * KT;
+            tap_bit = it_tap;
+            if (++it_tap == 9) { it_tap = 0; ++it_cb; }
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const float* src;
+            if (TAPS == 1) { src = a_ptr[it]; a_ptr[it] += KT; }
+            else src = ((a_taps[it] >> tap_bit) & 1) ? p.a + a_base[it] + tap_off : g_zero16;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(st + (it * 32 + wave_u * 8) * 128), 16, 0, 0);
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            __builtin_amdgcn_global_load_lds((gptr_t)b_ptr[it], (lptr_t)(st + APAN + (it * 32 + wave_u * 8) * 128), 16, 0, 0);
+            b_ptr[it] += KT;
+        }
+    };
+
+    const int sw = (lr >> 1) & 7;
+    const int a_row = (wm * 32 + lr) * 128, b_row = APAN + (wn * 32 + lr) * 128;
+    f32x16 acc[1][1];
+    auto compute = [&](const char* st) {
+        f32x4 fa[2], fb[2];
+        fa[0] = *reinterpret_cast<const f32x4*>(st + a_row + ((lh ^ sw) << 4));
+        fb[0] = *reinterpret_cast<const f32x4*>(st + b_row + ((lh ^ sw) << 4));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (u + 1 < 4) {
+                const int so = ((2 * (u + 1) + lh) ^ sw) << 4;
+                fa[(u + 1) & 1] = *reinterpret_cast<const f32x4*>(st + a_row + so);
+                fb[(u + 1) & 1] = *reinterpret_cast<const f32x4*>(st + b_row + so);
+            }
+            const f32x4 av = fa[u & 1], bv = fb[u & 1];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[0][0], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[0][0], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[0][0], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[0][0], 0, 0, 0);
+        }
+    };
+
+    setup_unit(unit);
+    issue_stage(smem);
+    while (true) {
+        const int m0c = m0, n0c = n0, tilec = tile_id, sharec = share, nstc = nst;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[0][0][q] = 0.f;
+        for (int kt = 0; kt < nstc; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (kt + 1 < nstc) issue_stage(smem + ((kt & 1) ^ 1) * STAGE);
+            compute(smem + (kt & 1) * STAGE);
+        }
+        const bool has_next = (unit + walk.stride) < walk.end;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // every wave is past its reads of the ring
+        if (has_next) {
+            unit += walk.stride;
+            setup_unit(unit);
+            issue_stage(smem);                           // next unit's first stage -> slot 0; the epilogue uses slot 1
+        }
+        if constexpr (!SPLIT) {
+            UAVSAL_GEMM_EPILOGUE(1.0f, (smem + STAGE), false)
+        } else {
+            // (1) publish: raw sums in register order, [tile][share][16 dwords x 256 threads], device-coherent stores
+            float* part = p.kpart + ((size_t)tilec * ksplit + sharec) * (BM * BN);
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const f32x4 v = {acc[0][0][4 * q4], acc[0][0][4 * q4 + 1], acc[0][0][4 * q4 + 2], acc[0][0][4 * q4 + 3]};
+                float* dst = part + (q4 * 256 + tid) * 4;
+                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(dst), "v"(v) : "memory");
+            }
+            // (2) every wave's stores have left, then ONE ticket per share (MI355X_MICROARCH.md, inter-workgroup
+            // visibility, counter form): the share that draws the last ticket reduces
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            int* ticket_lds = reinterpret_cast<int*>(smem + STAGE);
+            if (tid == 0) {
+                const int old = __hip_atomic_fetch_add(p.sk_flag + tilec, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int last = old == ksplit - 1;
+                if (last) {
+                    __hip_atomic_store(p.sk_flag + tilec, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                *ticket_lds = last;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            const bool reducer = *ticket_lds != 0;
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (reducer) {
+                // (3) all shares of the tile in share order (sc1 loads, one round), then through LDS to row order
+                const float* base = p.kpart + (size_t)tilec * ksplit * (BM * BN);
+#pragma unroll
+                for (int hq = 0; hq < 2; ++hq) {         // two rounds of 2 x ksplit loads (register budget)
+                    f32x4 t[MAXS][2];
+                    // (no branch around a load: a destination defined on one path only is merged by a copy BEFORE the
+                    // wait below, i.e. before the data has landed; absent shares re-read share 0 and are not added)
+#pragma unroll
+                    for (int sh = 0; sh < MAXS; ++sh) {
+                        const int she = sh < ksplit ? sh : 0;
+#pragma unroll
+                        for (int q = 0; q < 2; ++q)
+                            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(t[sh][q])
+                                         : "v"(base + (size_t)she * (BM * BN) + ((2 * hq + q) * 256 + tid) * 4) : "memory");
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)"
+                                 : "+v"(t[0][0]), "+v"(t[0][1]), "+v"(t[1][0]), "+v"(t[1][1]), "+v"(t[2][0]), "+v"(t[2][1]),
+                                   "+v"(t[3][0]), "+v"(t[3][1]) :: "memory");
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        f32x4 v = t[0][q];
+#pragma unroll
+                        for (int sh = 1; sh < MAXS; ++sh)
+                            if (sh < ksplit) v += t[sh][q];
+                        const int q4 = 2 * hq + q;
+                        acc[0][0][4 * q4] = v.x; acc[0][0][4 * q4 + 1] = v.y; acc[0][0][4 * q4 + 2] = v.z; acc[0][0][4 * q4 + 3] = v.w;
+                    }
+                }
+            }
+            // the reducing workgroup runs the ordinary epilogue on the summed tile (the others skip it as a whole:
+            // the decision is workgroup-uniform, so are the barriers inside)
+            if (reducer) UAVSAL_GEMM_EPILOGUE(1.0f, (smem + STAGE), false)
+        }
+        if (!has_next) break;
+    }
 }
 
 // may this launch split K (workspace there and large enough for 8 shares, epilogue the reduce step carries, vector
@@ -769,8 +977,9 @@ __attribute__((visibility("hidden"))) int uavsal_f32_k32_ksplit(long long tiles,
 }
 
 __attribute__((visibility("hidden"))) bool uavsal_f32_k32_eligible(const uavsal_conv_desc* d, int tile) {
-    if (tile < 8 || tile > 10) return false;
+    if (tile < 8 || tile > 11) return false;
     if (d->prec != UAVSAL_PREC_F32 || d->dw_w9c || d->epi == UAVSAL_EPI_LSTM) return false;
+    if (tile == 11 && d->epi == UAVSAL_EPI_TWA && ((d->ldx & 3) || (d->lda & 3) || (d->ldc & 3) || (d->Cout & 3))) return false;
     if ((d->Cin % 32) || d->Cin > UAVSAL_DWPROJ_MAX_C) return false;
     if (tile == 10) {      // the flat-pipeline kernel carries the vector affine epilogue; with K split (few tiles, long K,
                            // workspace given) the reducing share also does the ConvTWA update
@@ -790,8 +999,54 @@ __attribute__((visibility("hidden"))) bool uavsal_f32_k32_eligible(const uavsal_
     return d->taps == 1 || d->taps == 9;
 }
 
+namespace {
+// 64 x 64 tiles; K shares per tile (<= 4) when the workspace is there and the tiles alone leave most of the chip idle:
+// shares = the count that brings the work units to about two per CU of a 256-CU part (a function of the shape only)
+int launch_k32s(const ConvK& k0, int taps, hipStream_t stream) {
+    constexpr int SMEM = 2 * (64 + 64) * 128;
+    ConvK k = k0;
+    k.tiles_n = (k.Cout + 63) / 64;
+    k.nblk = ((k.M + 63) / 64) * k.tiles_n;
+    const int stages = k.Kpad / 32;
+    int ksp = 1;
+    if (k.kpart && k.sk_flag && (k.epi == UAVSAL_EPI_AFFINE || k.epi == UAVSAL_EPI_TWA) && k.nblk < 16000) {
+        ksp = (int)(1024 / (k.nblk > 0 ? k.nblk : 1));
+        if (ksp > 4) ksp = 4;
+        while (ksp > 1 && stages / ksp < 4) --ksp;
+        if (ksp < 1) ksp = 1;
+        if ((long long)k.nblk * ksp * 64 * 64 * 4 > k.kpart_bytes) ksp = 1;
+    }
+    k.ksplit = ksp;
+    auto cap_of = [](auto kernel) {
+        int per_cu = 0, cus = 0, dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return 256;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, SMEM) != hipSuccess || per_cu <= 0) per_cu = 1;
+        return per_cu * cus;
+    };
+    if (ksp > 1) {
+        k.nblk *= ksp;
+        static const int cap1 = cap_of(conv_gemm_f32_k32s_kernel<1, true>);
+        static const int cap9 = cap_of(conv_gemm_f32_k32s_kernel<9, true>);
+        const int cap = taps == 1 ? cap1 : cap9;
+        const int grid = k.nblk < cap ? k.nblk : cap;
+        if (taps == 1) hipLaunchKernelGGL((conv_gemm_f32_k32s_kernel<1, true>), dim3(grid), dim3(256), SMEM, stream, k);
+        else hipLaunchKernelGGL((conv_gemm_f32_k32s_kernel<9, true>), dim3(grid), dim3(256), SMEM, stream, k);
+    } else {
+        static const int cap1 = cap_of(conv_gemm_f32_k32s_kernel<1, false>);
+        static const int cap9 = cap_of(conv_gemm_f32_k32s_kernel<9, false>);
+        const int cap = taps == 1 ? cap1 : cap9;
+        const int grid = k.nblk < cap ? k.nblk : cap;
+        if (taps == 1) hipLaunchKernelGGL((conv_gemm_f32_k32s_kernel<1, false>), dim3(grid), dim3(256), SMEM, stream, k);
+        else hipLaunchKernelGGL((conv_gemm_f32_k32s_kernel<9, false>), dim3(grid), dim3(256), SMEM, stream, k);
+    }
+    return uavsal_launch_status();
+}
+}  // namespace
+
 __attribute__((visibility("hidden"))) int uavsal_launch_f32_k32(const uavsal_gemm::ConvK& k, int taps, int tile,
                                                                  hipStream_t stream) {
+    if (tile == 11) return launch_k32s(k, taps, stream);            // 64 x 64, K shares over workgroups, reduced in the launch
     if (tile == 10) return launch_k32<2, 2, 2, true>(k, taps, stream);    // 128 x 128, flat pipeline, 80 KB: two per CU
     if (tile == 9) return launch_k32<4, 2, 2>(k, taps, stream);     // 256 x 128 on 8 waves, one workgroup per CU
     return launch_k32<2, 2, 2>(k, taps, stream);                    // 128 x 128 on 4 waves, two per CU

@@ -371,7 +371,7 @@ class Engine:
             raise RuntimeError("%s: its input only exists as a split shadow but the GEMM is not eligible" % name)
         dwproj = int(self.lib.uavsal_conv_dwproj(C.byref(d)))
         tile = int(self.lib.uavsal_conv_tile(C.byref(d)))
-        d.w = self._convw(conv, wslice, gate_interleave, natural=split, dwproj=dwproj != 0, k32=tile in (8, 9, 10)).data_ptr()
+        d.w = self._convw(conv, wslice, gate_interleave, natural=split, dwproj=dwproj != 0, k32=tile in (8, 9, 10, 11)).data_ptr()
         self.ops_meta[-1]["split"] = split
         self.ops_meta[-1]["tile"] = tile
         self.ops_meta[-1]["streamk"] = int(self.lib.uavsal_conv_streamk_grid(C.byref(d)))

@@ -122,7 +122,7 @@ def conv_gemm(x, weight, scale=None, bias=None, act=L.ACT_NONE, res=None, out=No
     if split_in and not uses_split:
         raise RuntimeError("this shape / tile does not take the pre-split path")
     dwproj = int(lib.uavsal_conv_dwproj(C.byref(d))) != 0
-    k32 = prec == "f32" and int(lib.uavsal_conv_tile(C.byref(d))) in (8, 9, 10)     # 32-float K stages: 3x3 K order differs
+    k32 = prec == "f32" and int(lib.uavsal_conv_tile(C.byref(d))) in (8, 9, 10, 11)     # 32-float K stages: 3x3 K order differs
     wp = P.pack_conv_weight(weight, "f16x3i" if uses_split else ("f16x3j" if dwproj and prec == "f16x3" else
                                                                  ("f32k32" if k32 else prec))).to(x.device)
     keep.append(wp)
@@ -153,7 +153,7 @@ def twa_step(x_t, h_prev, pre_t, w_h, prec="f32", tile=0, stream_k=False):
         ws = torch.zeros(int(lib.uavsal_streamk_workspace_bytes()), dtype=torch.uint8, device=x_t.device)
         d.sk_ws, d.sk_ws_bytes = ws.data_ptr(), ws.numel()
     # weights last: the fp32 kernels with 32-float K stages (tiles 8-10) take the 3x3 K order in 32-channel blocks
-    k32 = prec == "f32" and int(lib.uavsal_conv_tile(C.byref(d))) in (8, 9, 10)
+    k32 = prec == "f32" and int(lib.uavsal_conv_tile(C.byref(d))) in (8, 9, 10, 11)
     wp = P.pack_conv_weight(w_h, "f32k32" if k32 else prec).to(x_t.device)
     d.w = wp.data_ptr()
     L.check(lib.uavsal_conv_gemm(C.byref(d), _stream(x_t)), "uavsal_conv_gemm(TWA)")

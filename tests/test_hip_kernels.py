@@ -231,7 +231,8 @@ def test_twa_step_f32_full_line_split_k(ops, shape):
     ref = gate * x + (1 - gate) * hp
     pre = ops.conv_gemm(nhwc(x), wt[:, :c].contiguous(), None, None, prec="f32")
     whole = ops.twa_step(nhwc(x), nhwc(hp), pre, wt[:, c:].contiguous(), prec="f32", tile=4)
-    for tile in (8, 10, 0):     # 8: shares + reduce launch; 10: flat pipeline, the last share to arrive reduces; 0: the default
+    for tile in (8, 10, 11, 0):     # 8: shares + reduce launch; 10: flat pipeline, the last share to arrive reduces;
+                                    # 11: 64 x 64 tiles, shares over workgroups, reduced in the launch; 0: the default
         split = ops.twa_step(nhwc(x), nhwc(hp), pre, wt[:, c:].contiguous(), prec="f32", tile=tile, stream_k=True)
         again = ops.twa_step(nhwc(x), nhwc(hp), pre, wt[:, c:].contiguous(), prec="f32", tile=tile, stream_k=True)
         assert torch.equal(split, again), tile                       # fixed summation order, whoever reduces
@@ -253,20 +254,20 @@ def test_conv_f32_full_line_split_k(ops, case):
     ref = act_ref(F.conv2d(x, wt, padding=kk // 2) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1), act)
     if use_res:
         ref = ref + res
-    for tile in (8, 10):
+    for tile in (8, 10, 11):
         got = ops.conv_gemm(nhwc(x), wt, scale, bias, act=act, res=nhwc(res) if use_res else None, prec="f32", tile=tile,
                             stream_k=True)
         assert (nchw(got) - ref).abs().max().item() <= TOL["f32"] * 4.0, (tile, case)
 
 
-@pytest.mark.parametrize("tile", [8, 9, 10])
+@pytest.mark.parametrize("tile", [8, 9, 10, 11])
 @pytest.mark.parametrize("case", [(2, 12, 20, 256, 1536, 1, 1, False), (1, 23, 40, 1536, 256, 1, 0, True),
                                   (3, 7, 5, 320, 256, 1, 1, False), (1, 45, 80, 32, 256, 1, 1, True),
                                   (2, 13, 17, 96, 200, 1, 0, False), (1, 12, 20, 64, 96, 9, 1, False),
                                   (2, 9, 13, 448, 256, 9, 1, False), (1, 45, 80, 256, 256, 9, 0, True)])
 def test_conv_f32_full_line_tiles(ops, tile, case):
-    """The fp32 kernels with 32-float (one cache line per row) K stages: 128 x 128 (8), 256 x 128 (9) and the flat
-    pipeline (10), 1x1 and 3x3 (weights packed with 32-channel K blocks), ragged M / N, residual."""
+    """The fp32 kernels with 32-float (one cache line per row) K stages: 128 x 128 (8), 256 x 128 (9), the flat
+    pipeline (10) and 64 x 64 (11; with the workspace: K shares over workgroups), 1x1 and 3x3 (weights packed with 32-channel K blocks), ragged M / N, residual."""
     n, h, w, cin, cout, taps, act, use_res = case
     kk = 3 if taps == 9 else 1
     x = rnd((n, cin, h, w), 58, 2.0)

@@ -56,7 +56,7 @@ def run(hw, n_img, cin, cout, taps, tile, iters=20, launches_only=0, act=1, stam
     h, w = hw
     a = torch.rand((n_img * h * w, cin), device=dev) * 2 - 1
     wt = (torch.rand((cout, cin, 3 if taps == 9 else 1, 3 if taps == 9 else 1)) - 0.5) * 0.1
-    wp = P.pack_conv_weight(wt, "f32k32" if tile in (8, 9, 10) else "f32").to(dev)
+    wp = P.pack_conv_weight(wt, "f32k32" if tile in (8, 9, 10, 11) else "f32").to(dev)
     out = torch.empty((n_img * h * w, cout), device=dev)
     s = torch.ones(P.roundup(cout, 32), device=dev)
     b = torch.zeros(P.roundup(cout, 32), device=dev)
@@ -68,6 +68,9 @@ def run(hw, n_img, cin, cout, taps, tile, iters=20, launches_only=0, act=1, stam
     d.n_img, d.H, d.W, d.Cin, d.Cout, d.taps = n_img, h, w, cin, cout, taps
     d.prec, d.act, d.epi, d.tile = L.PREC["f32"], act, 0, tile
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    if os.environ.get("PROBE_WS"):       # give the launch the K-split / stream-K workspace
+        ws = torch.zeros(int(lib.uavsal_streamk_workspace_bytes()), dtype=torch.uint8, device=dev)
+        d.sk_ws, d.sk_ws_bytes = ws.data_ptr(), ws.numel()
     if stamps:      # libuavsal_hip_stamps.so: the kernel adds its cycle sums into the K-split area of the workspace
         ws = torch.zeros(1 << 20, dtype=torch.uint8, device=dev)
         d.sk_ws, d.sk_ws_bytes = ws.data_ptr(), ws.numel()
@@ -114,7 +117,7 @@ def parts():
     names = {1: "full", 101: "no store", 116: "no epilogue", 102: "no MFMA", 104: "no DMA", 108: "no frag reads",
              106: "no MFMA, no DMA", 110: "no MFMA, no frag", 126: "K loop: DMA only", 124: "K loop: MFMA+frag only (no DMA, no epi)"}
     for sh in (((45, 80), 8, 256, 1536, 1), ((45, 80), 64, 256, 1536, 1), ((45, 80), 8, 4096, 1536, 1)):
-        for tile in (8, 9, 10):
+        for tile in (8, 9, 10, 11):
             for act, nm in names.items():
                 ms, tf = run(*sh, tile, act=act)
                 print("parts n=%d K=%d N=%d tile=%d %-42s %8.1f us" % (sh[1], sh[2], sh[3], tile, nm, ms * 1e3), flush=True)
@@ -146,6 +149,15 @@ if __name__ == "__main__":
         for sh in (SHAPES[0], SHAPES[1], SHAPES[5], SHAPES[6], SHAPES[7], SHAPES[9]):
             ms, tf = run(*sh, tl)
             print("n=%d K=%d N=%d taps=%d tile=%d: %8.1f us %6.1f TF" % (sh[1], sh[2], sh[3], sh[4], tl, ms * 1e3, tf), flush=True)
+        sys.exit(0)
+    if mode == "small":      # few tiles, long K: the backbone-tail projections, 64 x 64 instances (4 = 16-float stages)
+        for sh in (((12, 20), 8, 960, 160, 1), ((12, 20), 8, 960, 320, 1), ((12, 20), 8, 1920, 256, 1), ((12, 20), 8, 1024, 256, 1),
+                   ((23, 40), 8, 576, 96, 1), ((23, 40), 8, 384, 64, 1), ((23, 40), 1, 1536, 64, 1), ((12, 20), 8, 160, 960, 1)):
+            line = []
+            for tile in (0, 4, 8, 11):
+                ms, tf = run(*sh, tile)
+                line.append("t%d %6.1f us" % (tile, ms * 1e3))
+            print("hw=%s n=%d K=%d N=%d : %s" % (sh[0], sh[1], sh[2], sh[3], " | ".join(line)), flush=True)
         sys.exit(0)
     if mode == "pmc":
         tile = int(sys.argv[2])
