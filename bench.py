@@ -37,7 +37,8 @@ PEAK_HBM_GBS = 8000.0
 DTYPE_NAME = {"f32": "f32", "f16x3": "f32 (3x f16 split MFMA, f32 accumulate)",
               "bf16x3": "f32 (3x bf16 split MFMA, f32 accumulate)", "bf16": "bf16"}
 TILE_NAME = {1: "128x128", 2: "128x64", 3: "128x32", 4: "64x64", 5: "128x256", 6: "256x256", 7: "256x128",
-             8: "128x128 (32-float K stages)", 9: "256x128 (32-float K stages)", 10: "128x128 (32-float K stages, flat pipeline)"}
+             8: "128x128 (32-float K stages)", 9: "256x128 (32-float K stages)", 10: "128x128 (32-float K stages, flat pipeline)",
+             11: "64x64 (32-float K stages)"}
 PREC_ID = {"f32": 0, "bf16x3": 1, "bf16": 2, "f16x3": 3}
 # template arguments of the kernel instance each (precision, tile) launches, as rocprofv3 prints them
 F32_INST = {1: "2, 2, 2, 2, %d, 3, 1, false", 2: "4, 1, 1, 2, %d, 4, 1, false", 3: "4, 1, 1, 1, %d, 4, 1, false",
@@ -55,6 +56,8 @@ def kernel_symbol(prec, tile, taps, streamk=0, split=False):
         return "conv_gemm_h16_dma_kernel<%s>" % (H16_DMA_INST[tile] % taps)
     if prec == "f32" and tile in (8, 9, 10):      # conv_gemm_k32.hip
         return "conv_gemm_f32_k32%s_kernel<%s, 2, %d, 2>" % ("p" if tile == 10 else "", 4 if tile == 9 else 2, taps)
+    if prec == "f32" and tile == 11:              # 64 x 64; with the workspace the K-split instance (..., true>) may run
+        return "conv_gemm_f32_k32s_kernel<%d>" % taps
     if prec == "f32":
         return "conv_gemm_f32_dma_kernel<%s>" % ((F32_SK_INST if streamk else F32_INST)[tile] % taps)
     return "conv_gemm_kernel<%s>" % (H16_INST[tile] % (PREC_ID[prec], taps))

@@ -1456,6 +1456,12 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_gemm_h16_dma_k
     }
 }
 
+// K-split decisions count work units against a FIXED number of workgroup slots (two per CU of a 256-CU part), not against
+// what the occupancy query returns on the device at hand: the number of shares, hence the fp32 summation order, is a
+// function of the shape only (same results on every SKU / partition mode)
+#define UAVSAL_SPLIT_REF_SLOTS 512          /* dwproj_kernel's narrow instance: two workgroups per CU */
+#define UAVSAL_SPLIT_REF_SLOTS_64 1024      /* the register-staged 64 x 64 tiles (32 KB of LDS): four per CU */
+
 // resident workgroups per CU for one kernel instantiation (cached; queried once, outside any capture)
 template <typename K>
 int resident_grid(K kernel, int smem, int threads = 256) {
@@ -1489,7 +1495,7 @@ int launch_variant(const ConvK& k0, int taps, hipStream_t stream) {
         // (same K split as the 3x3 tile below: few 64 x 64 tiles, long K -- the 1920 -> 256 ASPP projections at 12x20)
         if (WM * WN == 1 && k.kpart && k.epi == UAVSAL_EPI_AFFINE && (PREC == UAVSAL_PREC_F16X3 || PREC == UAVSAL_PREC_BF16X3)) {
             static const bool on = [] { const char* e = getenv("UAVSAL_SPLITK_1X1"); return !(e && e[0] == '0'); }();
-            int ksp = on ? cap / (k.nblk > 0 ? k.nblk : 1) : 1;
+            int ksp = on ? UAVSAL_SPLIT_REF_SLOTS_64 / (k.nblk > 0 ? k.nblk : 1) : 1;
             ksp = ksp >= 4 ? 4 : (ksp >= 2 ? 2 : 1);
             while (ksp > 1 && (k.ktiles % ksp || k.ktiles / ksp < 12)) ksp >>= 1;
             if (ksp > 1 && (long long)ksp * k.M * k.Npad * 4 <= k.kpart_bytes && !(k.Cout & 3) && !(k.ldc & 3)) {
@@ -1507,7 +1513,7 @@ int launch_variant(const ConvK& k0, int taps, hipStream_t stream) {
         if (WM * WN == 1 && k.kpart && (k.epi == UAVSAL_EPI_TWA || k.epi == UAVSAL_EPI_AFFINE) &&
             (PREC == UAVSAL_PREC_F16X3 || PREC == UAVSAL_PREC_BF16X3)) {
             static const bool on = [] { const char* e = getenv("UAVSAL_SPLITK_3X3"); return !(e && e[0] == '0'); }();
-            int ksp = on ? cap / (k.nblk > 0 ? k.nblk : 1) : 1;
+            int ksp = on ? UAVSAL_SPLIT_REF_SLOTS_64 / (k.nblk > 0 ? k.nblk : 1) : 1;
             ksp = ksp >= 4 ? 4 : (ksp >= 2 ? 2 : 1);
             while (ksp > 1 && (k.ktiles % (9 * ksp) || k.ktiles / ksp < 18)) ksp >>= 1;
             if (ksp > 1 && (long long)ksp * k.M * k.Npad * 4 <= k.kpart_bytes && !(k.Cout & 3) && !(k.ldc & 3) &&
@@ -1672,7 +1678,7 @@ int launch_dwproj_variant(const ConvK& k0, hipStream_t stream) {
     // registers in fp32, and 7 MB of partial sums to re-read), so it is not split.
     k.ksplit = 1;
     if (BN <= 32 && k.kpart) {
-        int ksp = cap / (k.nblk > 0 ? k.nblk : 1);
+        int ksp = UAVSAL_SPLIT_REF_SLOTS / (k.nblk > 0 ? k.nblk : 1);
         if (ksp > 4) ksp = 4;
         while (ksp > 1 && (k.Cin / 16) / ksp < 12) --ksp;
         if (ksp > 1 && (long long)ksp * k.M * k.Npad * 4 <= k.kpart_bytes) k.ksplit = ksp;
@@ -1812,8 +1818,10 @@ static int effective_tile(const uavsal_conv_desc* d) {
         static const int k32_mode = [] { const char* e = getenv("UAVSAL_K32"); return e ? atoi(e) : 1; }();
         // (K of at least four 32-float stages: at K = 64 the 16-float instance is 1-2 us faster per launch -- three ring
         // stages against two -- and at K = 32 the launch is store-bound either way)
+        // (UAVSAL_K32_OVER_SK=1: also where the 16-float instance would run stream-K -- experiment knob)
+        static const int over_sk = [] { const char* e = getenv("UAVSAL_K32_OVER_SK"); return e ? atoi(e) : 0; }();
         if (k32_mode && uavsal_f32_k32_eligible(d, 8) && d->epi == UAVSAL_EPI_AFFINE && d->taps * d->Cin >= 128 &&
-            streamk_plan(d, 1, (d->taps * d->Cin + 15) / 16) == 0) {
+            (over_sk || streamk_plan(d, 1, (d->taps * d->Cin + 15) / 16) == 0)) {
             const long long M = (long long)d->H * d->W * d->n_img;
             tile = (k32_mode == 9 && d->Cout % 128 == 0 && ((M + 255) / 256) * (d->Cout / 128) >= 1024) ? 9 : 8;
         }

@@ -91,6 +91,7 @@ class Engine:
         self.sync_errors = bool(sync_errors)
         self._sk_ws = {}
         self._err = None
+        self._first_run_verified = False
         self._sk_debug = tuple(getattr(model, "_sk_debug", (0, 0)))
         # fused depthwise->projection GEMM (uavsal_conv_desc.dw_*): D never reaches HBM.
         #   None (default): the LDS-halo kernel (dwproj_kernel, fp32 and f16x3) on the blocks where it wins -- stride 1,
@@ -170,7 +171,10 @@ class Engine:
             t = torch.empty(n * h * w * c, dtype=torch.float32, device=self.device)
             self._keep.append(t)
             if name in self._split_want and c % 32 == 0:
-                sp = torch.empty(2 * n * h * w * c, dtype=torch.float16, device=self.device)
+                # NaN-filled, not empty: if a producer that cannot write shadows were ever added without entering
+                # its output in `_no_shadow`, the GEMM reading this shadow would multiply NaNs -- the first run of the
+                # plan then fails loudly (run(): `_verify_first_run`) instead of returning plausible wrong maps
+                sp = torch.full((2 * n * h * w * c,), float("nan"), dtype=torch.float16, device=self.device)
                 self._keep.append(sp)
         v = V(t, n, h, w, c, sp=sp, key=name)
         if name:
@@ -353,6 +357,12 @@ class Engine:
         d.n_img, d.H, d.W = n_img, a.h, a.w
         d.Cin, d.Cout, d.taps = cin, cout, taps
         d.prec, d.act, d.epi, d.tile = self.prec, act, epi, 0
+        # GEMMs on a side lane run beside grid-filling GEMMs of the main lane: the 64 x 64 instance with 32-float K stages
+        # needs 32 KB of LDS and 122 VGPRs, so one of its workgroups fits on a CU next to two of the main lane's
+        # (64 KB, 155 VGPRs each) instead of waiting for them to retire
+        side_tile = int(os.environ.get("UAVSAL_SIDE_TILE", "11"))      # (5.155 vs 5.17 ms per step, same box, two runs each)
+        if side_tile and self._lane != 0 and self.prec_name == "f32" and epi == L.EPI_AFFINE and dw is None and cin % 32 == 0:
+            d.tile = side_tile
         if out2 is not None:
             d.out2, d.ld2 = out2.ptr, out2.ld
         if self.stream_k:
@@ -903,6 +913,13 @@ class Engine:
             self.launch()
             if self.sync_errors:
                 self.check(wait=True)
+            if not self._first_run_verified and self.split_mode:
+                # once per plan: a split shadow nobody wrote (see _buf) shows up as NaN in the maps
+                self._first_run_verified = True
+                res = out if self.inplace else self.out
+                if bool(torch.isnan(res).any().item()) and not bool(torch.isnan(x.float()).any().item()):
+                    raise RuntimeError("the first run of this plan produced NaN maps from finite frames: a split shadow "
+                                       "was read that no producer wrote (engine._no_shadow is missing a buffer)")
             if not self.inplace:
                 out = self.out.clone()
                 if self.persistent:

@@ -117,7 +117,14 @@ typedef struct uavsal_conv_desc {
     int32_t Cin, Cout, taps;     /* taps: 1 or 9 */
     int32_t prec, act, epi;
     int32_t tile;                /* 0 = auto; else 1: 128x128, 2: 128x64, 3: 128x32, 4: 64x64, 5: 128x256, 6: 256x256 (split
-                                  * 16-bit precisions; others run them as 1), 7: 256x128 on 8 waves (F32; others as 1) */
+                                  * 16-bit precisions; others run them as 1), 7: 256x128 on 8 waves (F32; others as 1);
+                                  * F32 with Cin % 32 == 0, K stages of 32 floats = one cache line per tile row
+                                  * (conv_gemm_k32.hip; 3x3 weights then in the 'f32k32' K order, see `w`): 8: 128x128,
+                                  * 9: 256x128 on 8 waves, 10: 128x128 as one continuous stage stream (vector affine
+                                  * epilogue only), 11: 64x64.  With `sk_ws`, 8 / 10 / 11 split K over workgroups when
+                                  * the tiles alone would leave most of the chip idle (8: shares + reduce launch;
+                                  * 10, 11: the last share to arrive adds them in share order inside the launch).
+                                  * Shapes an instance cannot take fall back: 10 -> 8 -> 1, 9 -> 7, 11 -> 4. */
     float*       out2;   int32_t ld2;                 /* EPI_LSTM only: c_t (image stride = o_img_stride) */
     /* Fused depthwise producer (taps == 1, EPI_AFFINE): when dw_w9c != NULL, `a` is the EXPANDED tensor E
      * [n_img, dw_Hin, dw_Win, Cin] of an inverted-residual block and the GEMM's A operand is computed on the
@@ -167,7 +174,9 @@ typedef struct uavsal_conv_desc {
 } uavsal_conv_desc;
 
 int uavsal_conv_gemm(const uavsal_conv_desc* d, uavsal_stream_t stream);
-/* block tile `uavsal_conv_gemm` will use for this descriptor (1..7, see `tile`); no launch */
+/* block tile `uavsal_conv_gemm` will use for this descriptor (1..11, see `tile`); no launch.  Callers pack fp32
+ * 3x3 weights by it: tiles 8-11 take the K order with 32-channel blocks (k = ((ci / 32) * 9 + tap) * 32 + ci % 32,
+ * packing.py 'f32k32'), the others 16-channel blocks ('f32'); 1x1 weights are the same either way. */
 int uavsal_conv_tile(const uavsal_conv_desc* d);
 /* 1 when `uavsal_conv_gemm` will take the pre-split LDS-DMA path for this descriptor (a_split set, shape
  * eligible) and therefore expects `w` in the 'f16x3i' packing, else 0; no launch */

@@ -215,13 +215,16 @@ def test_lost_streamk_piece_raises_and_poisons(hip_model):
     with the test hook every producer withholds its flag, the owners' bounded wait gives up, the guard op
     overwrites map and state with NaN, and forward raises -- in the same call with sync_errors (default),
     at check_errors() / the next call without."""
-    x, cb = make_inputs(4, 96, 160)
+    # (at the benchmark size: the 3x3 convs of the head run stream-K there -- 450 tiles of 128 x 128; on small maps the
+    # launches that used to are now K-split instances that hand nothing over between resident workgroups)
+    T, H, W = 8, 360, 640
+    x, cb = make_inputs(T, H, W)
     args = (x.cuda(), [cb[0].cuda(), cb[1].cuda()], None)
-    hip_model.time_dims, hip_model.precision = 4, "f32"
+    hip_model.time_dims, hip_model.precision = T, "f32"
     good, _ = hip_model(*args)
     hip_model._sk_debug = (2000, -1)          # (poll limit, withhold every published flag)
     try:
-        eng_sk = sum(m.get("streamk", 0) > 0 for m in hip_model._engine(x.cuda().device, 1, 4, 96, 160, "tile").ops_meta)
+        eng_sk = sum(m.get("streamk", 0) > 0 for m in hip_model._engine(x.cuda().device, 1, T, H, W, "tile").ops_meta)
         assert eng_sk > 0, "no stream-K launch in this plan: the test would prove nothing"
         with pytest.raises(RuntimeError, match="stream-K"):
             hip_model(*args)
@@ -233,8 +236,8 @@ def test_lost_streamk_piece_raises_and_poisons(hip_model):
             hip_model.check_errors()          # ... and the error is reported at the next check
         # forward_clips (throughput surface) is asynchronous by default: poisoned result, error at the next check
         hip_model.sync_errors = None
-        xc = args[0].view(1, 4, 3, 96, 160)
-        oc, sc = hip_model.forward_clips(xc, [args[1][0].view(1, 4, 8, 12, 20), args[1][1].view(1, 4, 20, 12, 20)], None)
+        xc = args[0].view(1, T, 3, H, W)
+        oc, sc = hip_model.forward_clips(xc, [args[1][0].view(1, T, 8, H // 8, W // 8), args[1][1].view(1, T, 20, H // 8, W // 8)], None)
         torch.cuda.synchronize()
         assert torch.isnan(oc).all() and torch.isnan(sc).all()
         with pytest.raises(RuntimeError, match="stream-K"):
