@@ -580,6 +580,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW) void conv_gemm_f32_k3
             // (2) every wave's stores have left, then ONE ticket per share (MI355X_MICROARCH.md: inter-workgroup
             // visibility, the counter form); the share that draws the last ticket reduces
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (!p.sk_flag) continue;                    // the shares meet in splitk_reduce_kernel (second launch) instead
             int* ticket_lds = reinterpret_cast<int*>(smem + 2 * STAGE);
             if (tid == 0) {
                 const int old = __hip_atomic_fetch_add(p.sk_flag + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -925,6 +926,9 @@ int launch_k32(const ConvK& k0, int taps, hipStream_t stream) {
         k.ksplit = uavsal_f32_k32_split_ok(k) ? uavsal_f32_k32_ksplit(k.nblk, k.Kpad / 32) : 1;
         if (k.ksplit > 1) {          // (tile, K share) work units, reduced in the launch by the last share to arrive
             k.nblk *= k.ksplit;
+            // UAVSAL_K32_FLAT_REDUCE=launch: the shares are summed by splitk_reduce_kernel instead
+            static const bool by_launch = [] { const char* e = getenv("UAVSAL_K32_FLAT_REDUCE"); return e && e[0] == 'l'; }();
+            if (by_launch) k.sk_flag = nullptr;
             static const int cap1 = cap_of(conv_gemm_f32_k32p_kernel<WAVES_M, WAVES_N, 1, MINW, true>);
             static const int cap9 = cap_of(conv_gemm_f32_k32p_kernel<WAVES_M, WAVES_N, 9, MINW, true>);
             const int cap = taps == 1 ? cap1 : cap9;
@@ -933,6 +937,7 @@ int launch_k32(const ConvK& k0, int taps, hipStream_t stream) {
                 hipLaunchKernelGGL((conv_gemm_f32_k32p_kernel<WAVES_M, WAVES_N, 1, MINW, true>), dim3(grid), dim3(NT), SMEM, stream, k);
             else
                 hipLaunchKernelGGL((conv_gemm_f32_k32p_kernel<WAVES_M, WAVES_N, 9, MINW, true>), dim3(grid), dim3(NT), SMEM, stream, k);
+            if (!k.sk_flag) { k.nblk /= k.ksplit; return launch_splitk_reduce(k, 1.0f, stream); }
         } else if (taps == 1) {
             static const int cap = cap_of(conv_gemm_f32_k32p_kernel<WAVES_M, WAVES_N, 1, MINW>);
             const int grid = k.nblk < cap ? k.nblk : cap;

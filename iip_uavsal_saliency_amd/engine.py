@@ -244,6 +244,14 @@ class Engine:
         return t.contiguous().to(self.device)      # kept alive by the weight cache
 
     def _affine(self, bn, cout):
+        if isinstance(bn, (list, tuple)):        # several convs of the same input as ONE GEMM: outputs side by side
+            key = ("bn",) + tuple(id(b_) for b_ in bn) + (cout,)
+            if key not in self._wcache:
+                parts = [P.fold_bn(b_) for b_ in bn]
+                s, b = torch.cat([p_[0] for p_ in parts]), torch.cat([p_[1] for p_ in parts])
+                n = P.roundup(cout, 32)
+                self._wcache[key] = (self._dev(P.pad_vec(s, n, 1.0)), self._dev(P.pad_vec(b, n, 0.0)))
+            return self._wcache[key]
         key = ("bn", id(bn), cout)
         if key not in self._wcache:
             s, b = P.fold_bn(bn)
@@ -256,11 +264,12 @@ class Engine:
         `dwproj`: the split-fp16 depthwise -> projection kernel takes [K step of 16][Cout][hi 16 | lo 16] ('f16x3j');
         `k32`: fp32 kernels with 32-float K stages (tiles 8 / 9; differs from 'f32' for 3x3 weights only)."""
         layout = "f16x3i" if natural else ("f16x3j" if dwproj and self.prec_name == "f16x3" else self.prec_name)
-        if k32 and layout == "f32" and conv.weight.shape[-1] == 3:
+        multi = isinstance(conv, (list, tuple))
+        if k32 and layout == "f32" and (conv[0] if multi else conv).weight.shape[-1] == 3:
             layout = "f32k32"
-        key = ("w", id(conv), sl, layout, gate_interleave)
+        key = ("w",) + (tuple(id(c_) for c_ in conv) if multi else (id(conv),)) + (sl, layout, gate_interleave)
         if key not in self._wcache:
-            w = conv.weight.detach()
+            w = torch.cat([c_.weight.detach() for c_ in conv], 0) if multi else conv.weight.detach()
             if sl is not None:
                 w = w[:, sl[0]:sl[1]]
             if gate_interleave:      # ConvLSTM: row g*hid + c  ->  4*c + g  (gates i,f,o,g adjacent)
@@ -488,16 +497,20 @@ class Engine:
         self._add(self.lib.uavsal_plan_add_fused_ir, d, "plan_add_fused_ir(%s)" % name)
         return True
 
-    def ir_block(self, name, x: V, blk, out: V, final_act=L.ACT_NONE):
+    def ir_block(self, name, x: V, blk, out: V, final_act=L.ACT_NONE, expanded: Optional[V] = None):
         """pw-expand + BN + ReLU6 -> dw3x3 + BN + ReLU6 -> pw-linear + BN [+ x]
-        (dwBlock, reference model.py:74-103; torchvision InvertedResidual)."""
-        if final_act == L.ACT_NONE and self.fused_block(name, x, blk, out):
+        (dwBlock, reference model.py:74-103; torchvision InvertedResidual).
+        `expanded`: the block's expanded tensor already exists (several blocks' expands run as one GEMM)."""
+        if expanded is None and final_act == L.ACT_NONE and self.fused_block(name, x, blk, out):
             return
         seq = blk.conv
         stride, dil = blk.stride, getattr(blk, "dilation", 1)
         if blk.expand_ratio != 1:
-            e = self._scr("E", x.n, x.h, x.w, blk.hidden)
-            self.conv(name + ".pw", x, seq[0][0], seq[0][1], e, L.ACT_RELU6)
+            if expanded is not None:
+                e = expanded
+            else:
+                e = self._scr("E", x.n, x.h, x.w, blk.hidden)
+                self.conv(name + ".pw", x, seq[0][0], seq[0][1], e, L.ACT_RELU6)
             dwc, dwbn, pl, plbn = seq[1][0], seq[1][1], seq[2], seq[3]
         else:
             e = x
@@ -631,15 +644,23 @@ class Engine:
         x5 = self._buf("x5", N, c5.h, c5.w, 256)
         x4 = self._buf("x4", N, c4.h, c4.w, 128)
         cat = self._buf("srf_cat", N, h, w, 448)
-        self.fork(3)
-        self.ir_block("aspp2", c5, sf.lv5_aspp2, aspp.slice(256, 256))
-        self.main()
-        self.fork(4)
-        self.ir_block("aspp3", c5, sf.lv5_aspp3, aspp.slice(512, 256))
-        self.main()
-        self.fork(5)
-        self.ir_block("aspp4", c5, sf.lv5_aspp4, aspp.slice(768, 256))
-        self.main()
+        branches = (sf.lv5_aspp2, sf.lv5_aspp3, sf.lv5_aspp4)
+        if int(os.environ.get("UAVSAL_ASPP_MERGE", "1")) and all(b.expand_ratio != 1 for b in branches):
+            # the three dilated branches expand the SAME map with the same shape: one GEMM with their output channels
+            # side by side (320 -> 3 x 1920: 675 tiles instead of three launches of 225 fighting for the chip on three
+            # lanes), then every branch's depthwise + projection on its own lane, reading its slice
+            hid = branches[0].hidden
+            e3 = self._scr("E3", N, c5.h, c5.w, 3 * hid)
+            self.conv("aspp.pw", c5, [b.conv[0][0] for b in branches], [b.conv[0][1] for b in branches], e3, R6)
+            for bi, b in enumerate(branches):
+                self.fork(3 + bi)
+                self.ir_block("aspp%d" % (bi + 2), c5, b, aspp.slice(256 * (bi + 1), 256), expanded=e3.slice(bi * hid, hid))
+                self.main()
+        else:
+            for bi, b in enumerate(branches):
+                self.fork(3 + bi)
+                self.ir_block("aspp%d" % (bi + 2), c5, b, aspp.slice(256 * (bi + 1), 256))
+                self.main()
         self.fork(6)
         self.conv("conv_lv4", c4, sf.conv_lv4[0], sf.conv_lv4[1], x4, R6)
         self.bilinear("up_c4", x4, cat.slice(256, 128))

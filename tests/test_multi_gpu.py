@@ -117,3 +117,41 @@ def test_sharded_benchmark_shape_two_ranks():
     if n < 2:
         pytest.skip("needs 2 GPUs, %d visible" % n)
     _run_ranks(2, 16, "8,360,640")
+
+
+DEVICE_WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["UAVSAL_ROOT"])
+import torch
+from iip_uavsal_saliency_amd import UAVSal, synth
+T, H, W = 3, 72, 104
+h, w = H // 8, W // 8
+x = torch.from_numpy(synth.normalize_frames(synth.synth_frames_u8(T, H, W)))
+cb = [torch.from_numpy(synth.gauss_priors(T, h, w)), torch.from_numpy(synth.ob_priors(T, h, w))]
+model = UAVSal(time_dims=T)
+synth.load_synth_weights(model, 0)
+torch.cuda.set_device(0)                                   # the CURRENT device stays cuda:0 throughout
+m1 = model.to("cuda:1").eval()
+o1, s1 = m1(x.to("cuda:1"), [c.to("cuda:1") for c in cb], None)      # engine, plan, weights: all on cuda:1
+torch.cuda.synchronize("cuda:1")
+o1c, s1c = o1.cpu(), s1[0].cpu()
+ok = o1.device.index == 1 and s1[0].device.index == 1
+m0 = model.to("cuda:0").eval()                             # (moving the module drops the engines and packed weights)
+o0, s0 = m0(x.to("cuda:0"), [c.to("cuda:0") for c in cb], None)
+torch.cuda.synchronize("cuda:0")
+ok = ok and torch.equal(o1c, o0.cpu()) and torch.equal(s1c, s0[0].cpu())
+print("DEVICE_RESULT", "OK" if ok else "MISMATCH", flush=True)
+'''
+
+
+def test_engine_on_a_non_current_device():
+    """ADVICE r2: the launch plan's device resources (error word, `done` event, workspaces) and the packed weights
+    must live on the device of the frames, not on the current one: a forward on cuda:1 while cuda:0 is current, then
+    the same model on cuda:0 (the per-device weight cache must not hand cuda:1 pointers to the cuda:0 plan)."""
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip("needs 2 GPUs, %d visible" % n)
+    env = dict(os.environ, UAVSAL_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-c", DEVICE_WORKER], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    assert "DEVICE_RESULT OK" in p.stdout, p.stdout[-2000:]
