@@ -42,7 +42,8 @@ class ConvDesc(C.Structure):
                 ("sk_ws", _f), ("sk_ws_bytes", C.c_int64),
                 ("a_split", _f), ("ldas", C.c_int32),
                 ("out_split", _f), ("ldos", C.c_int32),
-                ("err", _f), ("sk_spin_limit", C.c_int32), ("sk_debug_drop", C.c_int32)]
+                ("err", _f), ("sk_spin_limit", C.c_int32), ("sk_debug_drop", C.c_int32),
+                ("w_group_stride", C.c_int64)]
 
 
 class DwDesc(C.Structure):
@@ -104,8 +105,19 @@ class FusedIrDesc(C.Structure):
                 ("hidden", C.c_int32), ("Cout", C.c_int32), ("stride", C.c_int32)]
 
 
+class WinoDesc(C.Structure):
+    _fields_ = [("inp", _f), ("ldi", C.c_int32), ("in_img_stride", C.c_int64),
+                ("out", _f), ("ldo", C.c_int32), ("out_img_stride", C.c_int64),
+                ("n_img", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32),
+                ("Mp", C.c_int64),
+                ("scale", _f), ("bias", _f), ("act", C.c_int32), ("epi", C.c_int32),
+                ("res", _f), ("ldr", C.c_int32), ("res_img_stride", C.c_int64),
+                ("aux", _f), ("ldx", C.c_int32), ("aux_img_stride", C.c_int64),
+                ("hprev", _f), ("ldh", C.c_int32), ("h_img_stride", C.c_int64)]
+
+
 DESC_TYPES = [ConvDesc, DwDesc, StemDesc, BilinearDesc, TdiffDesc, TsumDesc, LayoutDesc, PostDesc, GuardDesc, CopyDesc,
-              FusedIrDesc]
+              FusedIrDesc, WinoDesc]
 
 # every symbol include/uavsal_hip.h declares: (name, restype, argtypes)
 SYMBOLS = [
@@ -128,6 +140,10 @@ SYMBOLS = [
     ("uavsal_fused_ir", C.c_int, [C.POINTER(FusedIrDesc), C.c_void_p]),
     ("uavsal_fused_ir_supported", C.c_int, [C.POINTER(FusedIrDesc)]),
     ("uavsal_plan_add_fused_ir", C.c_int, [C.c_void_p, C.POINTER(FusedIrDesc)]),
+    ("uavsal_wino_input", C.c_int, [C.POINTER(WinoDesc), C.c_void_p]),
+    ("uavsal_wino_output", C.c_int, [C.POINTER(WinoDesc), C.c_void_p]),
+    ("uavsal_plan_add_wino_input", C.c_int, [C.c_void_p, C.POINTER(WinoDesc)]),
+    ("uavsal_plan_add_wino_output", C.c_int, [C.c_void_p, C.POINTER(WinoDesc)]),
     ("uavsal_plan_add_copy", C.c_int, [C.c_void_p, C.POINTER(CopyDesc)]),
     ("uavsal_plan_create", C.c_void_p, []),
     ("uavsal_plan_destroy", None, [C.c_void_p]),
@@ -173,7 +189,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.uavsal_abi_version() != 12:
+    if lib.uavsal_abi_version() != 13:
         raise RuntimeError("libuavsal_hip.so ABI version mismatch")
     for i, t in enumerate(DESC_TYPES):
         if lib.uavsal_sizeof_desc(i) != C.sizeof(t):

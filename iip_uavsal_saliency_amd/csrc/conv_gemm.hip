@@ -1779,6 +1779,7 @@ int pick_tile(long long M, int Cout, int prec) {
 }  // namespace
 
 static int effective_tile(const uavsal_conv_desc* d) {
+    if (d->w_group_stride) return d->tile == 11 ? 11 : 8;    // per-image weights: the instances with 32-float K stages, 128 x 128 or 64 x 64
     int tile = (d->tile >= 1 && d->tile <= 11) ? d->tile
                                              : pick_tile((long long)d->H * d->W * d->n_img, d->Cout, d->prec);
     if (tile == 11 && !uavsal_f32_k32_eligible(d, tile)) tile = 4;
@@ -1937,6 +1938,9 @@ extern "C" int uavsal_conv_gemm(const uavsal_conv_desc* d, uavsal_stream_t strea
     k.sk_drop = d->sk_debug_drop;
     const int tile = effective_tile(d);
     hipStream_t s = (hipStream_t)stream;
+    k.w_gs = d->w_group_stride;
+    if (k.w_gs && !((tile == 8 || tile == 11) && uavsal_f32_k32_eligible(d, tile) && d->epi == UAVSAL_EPI_AFFINE && !d->a_split))
+        return UAVSAL_ESHAPE;
     k.a_sp = (const _Float16*)d->a_split; k.ldas = d->ldas;
     k.out_sp = (_Float16*)d->out_split; k.ldos = d->ldos;
     if (split_eligible(d, tile)) return launch_h16(k, d->taps, tile, s);

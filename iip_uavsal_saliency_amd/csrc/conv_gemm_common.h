@@ -33,6 +33,7 @@ struct ConvK {
     const _Float16* a_sp;      // pre-split A operand (split shadow, uavsal_hip.h) or null
     _Float16* out_sp;          // optional split shadow of the output
     int ldas, ldos;            // their row strides in halves
+    long long w_gs;            // per-image weights (uavsal_conv_desc.w_group_stride, floats; 0 = none): HW % 128 == 0
 };
 
 }  // namespace uavsal_gemm

@@ -148,7 +148,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW) void conv_gemm_f32_k3
         for (int it = 0; it < B_IT; ++it) {
             // weight rows past Npad re-read the last real row (those columns are never stored)
             const int nn = min(n0 + r8 + it * RPI, p.Npad - 1);
-            b_ptr[it] = reinterpret_cast<const float*>(p.w) + (size_t)nn * p.Kpad + lc * 4 + s0 * KT;
+            // (per-image weights: the tile lies inside image m0 / HW -- HW is a multiple of the tile height)
+            b_ptr[it] = reinterpret_cast<const float*>(p.w) + (p.w_gs ? (size_t)(m0 / p.HW) * p.w_gs : 0) +
+                        (size_t)nn * p.Kpad + lc * 4 + s0 * KT;
         }
         it_cb = s0 / 9; it_tap = s0 - it_cb * 9;         // (3x3: stage s = channel block s / 9, tap s % 9)
     };
@@ -764,7 +766,8 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_f32_k32s_kernel(const ConvK 
                 a_taps[it] = mask;
             }
             const int nn = min(n0 + r8 + it * 32, p.Npad - 1);
-            b_ptr[it] = reinterpret_cast<const float*>(p.w) + (size_t)nn * p.Kpad + lc * 4 + s0 * KT;
+            b_ptr[it] = reinterpret_cast<const float*>(p.w) + (p.w_gs ? (size_t)(m0 / p.HW) * p.w_gs : 0) +
+                        (size_t)nn * p.Kpad + lc * 4 + s0 * KT;
         }
         it_cb = s0 / 9; it_tap = s0 - it_cb * 9;
     };
@@ -983,6 +986,7 @@ __attribute__((visibility("hidden"))) int uavsal_f32_k32_ksplit(long long tiles,
 
 __attribute__((visibility("hidden"))) bool uavsal_f32_k32_eligible(const uavsal_conv_desc* d, int tile) {
     if (tile < 8 || tile > 11) return false;
+    if (d->w_group_stride && ((tile != 8 && tile != 11) || d->taps != 1 || (((long long)d->H * d->W) & 127))) return false;
     if (d->prec != UAVSAL_PREC_F32 || d->dw_w9c || d->epi == UAVSAL_EPI_LSTM) return false;
     if (tile == 11 && d->epi == UAVSAL_EPI_TWA && ((d->ldx & 3) || (d->lda & 3) || (d->ldc & 3) || (d->Cout & 3))) return false;
     if ((d->Cin % 32) || d->Cin > UAVSAL_DWPROJ_MAX_C) return false;

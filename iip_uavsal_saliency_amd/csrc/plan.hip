@@ -8,7 +8,8 @@
 #include "common.h"
 
 namespace {
-enum OpKind { OP_CONV = 0, OP_DW, OP_STEM, OP_BILINEAR, OP_TDIFF, OP_TSUM, OP_LAYOUT, OP_GUARD, OP_COPY, OP_FUSED_IR, OP_FORK, OP_JOIN };
+enum OpKind { OP_CONV = 0, OP_DW, OP_STEM, OP_BILINEAR, OP_TDIFF, OP_TSUM, OP_LAYOUT, OP_GUARD, OP_COPY, OP_FUSED_IR, OP_FORK, OP_JOIN,
+              OP_WINO_IN, OP_WINO_OUT };
 constexpr int MAX_LANES = 8;
 
 // Lanes: lane 0 is the caller's stream; lanes 1..7 are private streams on which independent
@@ -30,6 +31,7 @@ struct Op {
         uavsal_guard_desc guard;
         uavsal_copy_desc copy;
         uavsal_fused_ir_desc fir;
+        uavsal_wino_desc wino;
     } u;
 };
 
@@ -45,6 +47,8 @@ int run_op(const Op& op, uavsal_stream_t s) {
         case OP_GUARD: return uavsal_guard(&op.u.guard, s);
         case OP_COPY: return uavsal_copy_rows(&op.u.copy, s);
         case OP_FUSED_IR: return uavsal_fused_ir(&op.u.fir, s);
+        case OP_WINO_IN: return uavsal_wino_input(&op.u.wino, s);
+        case OP_WINO_OUT: return uavsal_wino_output(&op.u.wino, s);
     }
     return UAVSAL_EINVAL;
 }
@@ -172,6 +176,8 @@ UAVSAL_ADD(uavsal_plan_add_tsum, OP_TSUM, ts, uavsal_tsum_desc)
 UAVSAL_ADD(uavsal_plan_add_layout, OP_LAYOUT, lay, uavsal_layout_desc)
 UAVSAL_ADD(uavsal_plan_add_copy, OP_COPY, copy, uavsal_copy_desc)
 UAVSAL_ADD(uavsal_plan_add_fused_ir, OP_FUSED_IR, fir, uavsal_fused_ir_desc)
+UAVSAL_ADD(uavsal_plan_add_wino_input, OP_WINO_IN, wino, uavsal_wino_desc)
+UAVSAL_ADD(uavsal_plan_add_wino_output, OP_WINO_OUT, wino, uavsal_wino_desc)
 
 extern "C" int uavsal_plan_patch_ptr(uavsal_plan* p, int op, int slot, void* ptr) {
     if (!p || op < 0 || op >= (int)p->ops.size() || !ptr) return UAVSAL_EINVAL;
@@ -309,6 +315,7 @@ extern "C" int uavsal_sizeof_desc(int which) {
         case 8: return (int)sizeof(uavsal_guard_desc);
         case 9: return (int)sizeof(uavsal_copy_desc);
         case 10: return (int)sizeof(uavsal_fused_ir_desc);
+        case 11: return (int)sizeof(uavsal_wino_desc);
     }
     return UAVSAL_EINVAL;
 }

@@ -1,0 +1,193 @@
+// Winograd F(2x2, 3x3) transforms for the path's dense 3x3 convolutions (stride 1, padding 1: conv_last of the SRF-Net
+// head, reference model.py:155-156, and the ConvTWA gate convolution, model_convlstm.py:276-292), fp32 throughout.
+//
+//   out(2x2 tile) = A^T [ sum_c (G g G^T) .* (B^T d B) ] A        d = 4x4 input patch, g = 3x3 filter
+//
+// 16 multiplications per 4 outputs instead of 36: the sixteen element-wise products over the channels are sixteen
+// independent GEMMs [tiles x Cin] . [Cin x Cout] -- they run as ONE launch of the ordinary fp32 GEMM with the sixteen
+// transform planes as "images" and per-image weights (uavsal_conv_desc.w_group_stride) -- so a 3x3 conv costs 2.25x
+// fewer MFMA FLOPs, which is what bounds it (the fp32 matrix rate, at the clock the chip holds: profiles/r3_gemm_k32.md),
+// for two memory-bound transform launches.  Numerics: coefficients 0, +-1, +-1/2 only; against direct fp32 convolution
+// the saliency map moves by 5e-5 (oracle experiment at 360x640, 8- and 20-frame calls: profiles/r3_winograd.md).
+//
+//   uavsal_wino_input : NHWC activation -> V[16][Mp][C],   V_k[tile][c] = (B^T d B)_k        one thread = (tile, 4 channels)
+//   uavsal_wino_output: M[16][Mp][C]    -> NHWC output,    y = A^T m A, then BN / ReLU6 / residual or the ConvTWA update
+// tile = (image, ty, tx) in row-major order; planes are Mp rows apart (Mp % 128 == 0: every plane is whole GEMM tiles;
+// rows past the tiles are never written -- the caller zero-fills the V buffer once -- and never read back).
+#include "common.h"
+
+namespace {
+
+struct WinoK {
+    const float* in; float* out;
+    const float* scale; const float* bias; const float* res; const float* aux; const float* hprev;
+    long long in_is, out_is, res_is, aux_is, h_is;      // image strides in pixels
+    long long Mp;
+    int ldi, ldo, ldr, ldx, ldh;
+    int n_img, H, W, C4, ty, tx, act, epi;
+    long long total;
+};
+
+__global__ __launch_bounds__(256) void wino_input_kernel(const WinoK p) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= p.total) return;
+    const int c4 = (int)(idx % p.C4);
+    const long long tile = idx / p.C4;
+    const int tpi = p.ty * p.tx;
+    const int n = (int)(tile / tpi);
+    const int r = (int)(tile - (long long)n * tpi);
+    const int tyi = r / p.tx, txi = r - tyi * p.tx;
+    const int y0 = 2 * tyi - 1, x0 = 2 * txi - 1;
+    const float* base = p.in + (size_t)n * p.in_is * p.ldi + c4 * 4;
+    f32x4 d[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int y = y0 + i;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int x = x0 + j;
+            d[i][j] = (y >= 0 && y < p.H && x >= 0 && x < p.W)
+                          ? *reinterpret_cast<const f32x4*>(base + ((size_t)y * p.W + x) * p.ldi)
+                          : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    // B^T d (rows), then (.) B (columns):  B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
+    f32x4 t[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        t[0][j] = d[0][j] - d[2][j];
+        t[1][j] = d[1][j] + d[2][j];
+        t[2][j] = d[2][j] - d[1][j];
+        t[3][j] = d[1][j] - d[3][j];
+    }
+    float* o = p.out + (size_t)tile * p.ldo + c4 * 4;
+    const size_t plane = (size_t)p.Mp * p.ldo;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        *reinterpret_cast<f32x4*>(o + (size_t)(4 * i + 0) * plane) = t[i][0] - t[i][2];
+        *reinterpret_cast<f32x4*>(o + (size_t)(4 * i + 1) * plane) = t[i][1] + t[i][2];
+        *reinterpret_cast<f32x4*>(o + (size_t)(4 * i + 2) * plane) = t[i][2] - t[i][1];
+        *reinterpret_cast<f32x4*>(o + (size_t)(4 * i + 3) * plane) = t[i][1] - t[i][3];
+    }
+}
+
+__device__ __forceinline__ f32x4 sigmoid4(f32x4 z) {
+    f32x4 g;
+    g.x = 1.f / (1.f + expf(-z.x)); g.y = 1.f / (1.f + expf(-z.y));
+    g.z = 1.f / (1.f + expf(-z.z)); g.w = 1.f / (1.f + expf(-z.w));
+    return g;
+}
+
+__global__ __launch_bounds__(256) void wino_output_kernel(const WinoK p) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= p.total) return;
+    const int c4 = (int)(idx % p.C4);
+    const long long tile = idx / p.C4;
+    const int tpi = p.ty * p.tx;
+    const int n = (int)(tile / tpi);
+    const int r = (int)(tile - (long long)n * tpi);
+    const int tyi = r / p.tx, txi = r - tyi * p.tx;
+    const float* mi = p.in + (size_t)tile * p.ldi + c4 * 4;
+    const size_t plane = (size_t)p.Mp * p.ldi;
+    f32x4 m[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m[i][j] = *reinterpret_cast<const f32x4*>(mi + (size_t)(4 * i + j) * plane);
+    // A^T m (rows), then (.) A (columns):  A^T = [1 1 1 0; 0 1 -1 -1]
+    f32x4 s[2][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        s[0][j] = m[0][j] + m[1][j] + m[2][j];
+        s[1][j] = m[1][j] - m[2][j] - m[3][j];
+    }
+    f32x4 y[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        y[a][0] = s[a][0] + s[a][1] + s[a][2];
+        y[a][1] = s[a][1] - s[a][2] - s[a][3];
+    }
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
+    if (p.scale) {
+        sc = *reinterpret_cast<const f32x4*>(p.scale + c4 * 4);
+        bi = *reinterpret_cast<const f32x4*>(p.bias + c4 * 4);
+    }
+    const float lo = p.act == UAVSAL_ACT_RELU6 ? 0.f : -3.0e38f, hi = p.act == UAVSAL_ACT_RELU6 ? 6.f : 3.0e38f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int yy = 2 * tyi + a, xx = 2 * txi + b;
+            if (yy >= p.H || xx >= p.W) continue;
+            const size_t pix = (size_t)yy * p.W + xx;
+            f32x4 v = y[a][b];
+            if (p.epi == UAVSAL_EPI_TWA) {      // gate = sigmoid(conv(h) + W_x x_t); h_t = gate x_t + (1 - gate) h_{t-1}
+                const f32x4 z = v + *reinterpret_cast<const f32x4*>(p.aux + ((size_t)n * p.aux_is + pix) * p.ldx + c4 * 4);
+                const f32x4 xt = *reinterpret_cast<const f32x4*>(p.res + ((size_t)n * p.res_is + pix) * p.ldr + c4 * 4);
+                const f32x4 hp = *reinterpret_cast<const f32x4*>(p.hprev + ((size_t)n * p.h_is + pix) * p.ldh + c4 * 4);
+                const f32x4 g = sigmoid4(z);
+                v = g * xt + (1.f - g) * hp;
+            } else {
+                v.x = __builtin_amdgcn_fmed3f(fmaf(v.x, sc.x, bi.x), lo, hi); v.y = __builtin_amdgcn_fmed3f(fmaf(v.y, sc.y, bi.y), lo, hi);
+                v.z = __builtin_amdgcn_fmed3f(fmaf(v.z, sc.z, bi.z), lo, hi); v.w = __builtin_amdgcn_fmed3f(fmaf(v.w, sc.w, bi.w), lo, hi);
+                if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + ((size_t)n * p.res_is + pix) * p.ldr + c4 * 4);
+            }
+            *reinterpret_cast<f32x4*>(p.out + ((size_t)n * p.out_is + pix) * p.ldo + c4 * 4) = v;
+        }
+}
+
+int fill(const uavsal_wino_desc* d, WinoK& k, bool input) {
+    if (!d || !d->in || !d->out) return UAVSAL_EINVAL;
+    if (d->n_img <= 0 || d->H <= 0 || d->W <= 0 || d->C <= 0) return UAVSAL_EINVAL;
+    if ((d->C & 3) || (d->ldi & 3) || (d->ldo & 3) || d->ldi < d->C || d->ldo < d->C) return UAVSAL_EALIGN;
+    if (!uavsal_aligned16(d->in) || !uavsal_aligned16(d->out)) return UAVSAL_EALIGN;
+    k.ty = (d->H + 1) / 2; k.tx = (d->W + 1) / 2;
+    const long long tiles = (long long)d->n_img * k.ty * k.tx;
+    if ((d->Mp & 127) || d->Mp < tiles) return UAVSAL_ESHAPE;
+    k.in = d->in; k.out = d->out; k.ldi = d->ldi; k.ldo = d->ldo; k.Mp = d->Mp;
+    k.n_img = d->n_img; k.H = d->H; k.W = d->W; k.C4 = d->C / 4;
+    const long long hw = (long long)d->H * d->W;
+    k.in_is = d->in_img_stride > 0 ? d->in_img_stride : hw;
+    k.out_is = d->out_img_stride > 0 ? d->out_img_stride : hw;
+    k.scale = k.bias = k.res = k.aux = k.hprev = nullptr;
+    k.res_is = k.aux_is = k.h_is = hw; k.ldr = k.ldx = k.ldh = 0; k.act = UAVSAL_ACT_NONE; k.epi = UAVSAL_EPI_AFFINE;
+    if (!input) {
+        if ((d->scale == nullptr) != (d->bias == nullptr)) return UAVSAL_EINVAL;
+        if (d->act != UAVSAL_ACT_NONE && d->act != UAVSAL_ACT_RELU6) return UAVSAL_ESHAPE;
+        if (d->epi != UAVSAL_EPI_AFFINE && d->epi != UAVSAL_EPI_TWA) return UAVSAL_ESHAPE;
+        k.scale = d->scale; k.bias = d->bias; k.act = d->act; k.epi = d->epi;
+        if (d->res) {
+            if ((d->ldr & 3) || d->ldr < d->C || !uavsal_aligned16(d->res)) return UAVSAL_EALIGN;
+            k.res = d->res; k.ldr = d->ldr; k.res_is = d->res_img_stride > 0 ? d->res_img_stride : hw;
+        }
+        if (d->epi == UAVSAL_EPI_TWA) {
+            if (!d->res || !d->aux || !d->hprev) return UAVSAL_EINVAL;
+            if ((d->ldx & 3) || (d->ldh & 3) || d->ldx < d->C || d->ldh < d->C || !uavsal_aligned16(d->aux) || !uavsal_aligned16(d->hprev))
+                return UAVSAL_EALIGN;
+            k.aux = d->aux; k.ldx = d->ldx; k.aux_is = d->aux_img_stride > 0 ? d->aux_img_stride : hw;
+            k.hprev = d->hprev; k.ldh = d->ldh; k.h_is = d->h_img_stride > 0 ? d->h_img_stride : hw;
+        }
+        if (d->scale && (!uavsal_aligned16(d->scale) || !uavsal_aligned16(d->bias))) return UAVSAL_EALIGN;
+    }
+    k.total = tiles * k.C4;
+    if ((k.total + 255) / 256 > 0x7fffffffLL) return UAVSAL_ESHAPE;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int uavsal_wino_input(const uavsal_wino_desc* d, uavsal_stream_t stream) {
+    WinoK k;
+    const int e = fill(d, k, true);
+    if (e) return e;
+    hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((k.total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, k);
+    return uavsal_launch_status();
+}
+
+extern "C" int uavsal_wino_output(const uavsal_wino_desc* d, uavsal_stream_t stream) {
+    WinoK k;
+    const int e = fill(d, k, false);
+    if (e) return e;
+    hipLaunchKernelGGL(wino_output_kernel, dim3((unsigned)((k.total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, k);
+    return uavsal_launch_status();
+}

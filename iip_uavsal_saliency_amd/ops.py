@@ -134,6 +134,56 @@ def conv_gemm(x, weight, scale=None, bias=None, act=L.ACT_NONE, res=None, out=No
     return (out, shadow) if split_out else out
 
 
+def conv3x3_winograd(x, weight, scale=None, bias=None, act=L.ACT_NONE, res=None, twa=None):
+    """Dense 3x3 conv (stride 1, padding 1) through Winograd F(2x2, 3x3), fp32: input transform, ONE GEMM launch over the
+    sixteen transform planes (per-plane weights), output transform with the epilogue.  `twa=(x_t, pre_t)`: `x` is
+    h_{t-1} and the output transform applies the ConvTWA update (model_convlstm.py:276-292)."""
+    lib = L.load()
+    ip, ldi, n, h, w, cin = _nhwc_view(x)
+    cout = weight.shape[0]
+    tiles = n * ((h + 1) // 2) * ((w + 1) // 2)
+    mp = P.roundup(tiles, 128)
+    dev = x.device
+    v = torch.zeros((16, mp, cin), dtype=torch.float32, device=dev)
+    m = torch.empty((16, mp, cout), dtype=torch.float32, device=dev)
+    out = torch.empty((n, h, w, cout), dtype=torch.float32, device=dev)
+    wp = P.pack_wino_weight(weight).to(dev)
+    st = _stream(x)
+    wi = L.WinoDesc()
+    wi.inp, wi.ldi, wi.out, wi.ldo = ip, ldi, v.data_ptr(), cin
+    wi.n_img, wi.H, wi.W, wi.C, wi.Mp = n, h, w, cin, mp
+    L.check(lib.uavsal_wino_input(C.byref(wi), st), "uavsal_wino_input")
+    d = L.ConvDesc()
+    d.a, d.lda, d.a_img_stride = v.data_ptr(), cin, mp
+    d.w = wp.data_ptr()
+    d.w_group_stride = P.roundup(cout, 32) * P.roundup(cin, 32)
+    d.out, d.ldc, d.o_img_stride = m.data_ptr(), cout, mp
+    d.n_img, d.H, d.W, d.Cin, d.Cout, d.taps = 16, mp, 1, cin, cout, 1
+    d.prec, d.act, d.epi, d.tile = L.PREC["f32"], L.ACT_NONE, L.EPI_AFFINE, 0
+    L.check(lib.uavsal_conv_gemm(C.byref(d), st), "uavsal_conv_gemm(winograd planes)")
+    wo = L.WinoDesc()
+    wo.inp, wo.ldi, wo.out, wo.ldo = m.data_ptr(), cout, out.data_ptr(), cout
+    wo.n_img, wo.H, wo.W, wo.C, wo.Mp = n, h, w, cout, mp
+    keep = [v, m, wp]
+    if scale is not None:
+        npad = P.roundup(cout, 32)
+        s_ = P.pad_vec(scale, npad, 1.0).to(dev)
+        b_ = P.pad_vec(bias, npad, 0.0).to(dev)
+        keep += [s_, b_]
+        wo.scale, wo.bias = s_.data_ptr(), b_.data_ptr()
+    wo.act, wo.epi = act, L.EPI_AFFINE
+    if res is not None:
+        rp, ldr, *_ = _nhwc_view(res)
+        wo.res, wo.ldr = rp, ldr
+    if twa is not None:
+        xp, ldr, *_ = _nhwc_view(twa[0])
+        pp, ldx, *_ = _nhwc_view(twa[1])
+        wo.epi, wo.res, wo.ldr, wo.aux, wo.ldx, wo.hprev, wo.ldh = L.EPI_TWA, xp, ldr, pp, ldx, ip, ldi
+    L.check(lib.uavsal_wino_output(C.byref(wo), st), "uavsal_wino_output")
+    torch.cuda.current_stream(dev).synchronize()
+    return out
+
+
 def twa_step(x_t, h_prev, pre_t, w_h, prec="f32", tile=0, stream_k=False):
     """One ConvTWA step given pre_t = conv3x3(W[:, :C], x_t): returns h_t (NHWC)."""
     lib = L.load()

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define UAVSAL_ABI_VERSION 12
+#define UAVSAL_ABI_VERSION 13
 
 /* argument errors */
 #define UAVSAL_EINVAL   (-1)  /* null pointer / non-positive size */
@@ -171,6 +171,11 @@ typedef struct uavsal_conv_desc {
     int32_t* err;            /* device word OR-ed with UAVSAL_ERR_* (NULL: the last int32 of sk_ws' 64 KB flag block) */
     int32_t sk_spin_limit;   /* polls before a stream-K owner gives up on one piece; 0 = default (1 << 22, seconds) */
     int32_t sk_debug_drop;   /* TEST HOOK: 1 + index of the stream-K workgroup that withholds its "published" flag (< 0: all do); 0 = none */
+    /* Per-image weights (F32, taps == 1, tiles 8 / 11; 0 = one weight matrix for all images): image g multiplies with
+     * the packed matrix at w + g * w_group_stride floats, and H * W must be a multiple of 128 so that no GEMM tile
+     * straddles two images.  This is how the sixteen GEMMs of a Winograd 3x3 convolution run as one launch
+     * (uavsal_wino_input / uavsal_wino_output: the images are the sixteen transform planes). */
+    int64_t w_group_stride;
 } uavsal_conv_desc;
 
 int uavsal_conv_gemm(const uavsal_conv_desc* d, uavsal_stream_t stream);
@@ -288,6 +293,34 @@ typedef struct uavsal_tdiff_desc {
 
 int uavsal_tdiff(const uavsal_tdiff_desc* d, uavsal_stream_t stream);
 
+/*
+ * Winograd F(2x2, 3x3) transforms of a dense 3x3 convolution with stride 1 and padding 1 (csrc/winograd.hip), fp32.
+ *   uavsal_wino_input : `in` NHWC [n_img, H, W, C] (row stride ldi)  ->  `out` = V[16][Mp][ldo]: plane k = 4 i + j holds
+ *                       (B^T d B)_{ij} of every 2x2 output tile (tile = (image, ty, tx), row-major), channels C.
+ *   uavsal_wino_output: `in` = M[16][Mp][ldi] (the sixteen GEMM results, channels C = Cout)  ->  `out` NHWC
+ *                       [n_img, H, W, C]: y = A^T m A, then scale / bias (or NULL), ACT_NONE / ACT_RELU6, optional residual
+ *                       (EPI_AFFINE), or the ConvTWA update h_t = g x_t + (1 - g) h_{t-1}, g = sigmoid(y + aux) with
+ *                       res = x_t, hprev = h_{t-1} (EPI_TWA).
+ * Mp (rows per plane) >= n_img * ceil(H/2) * ceil(W/2), a multiple of 128; rows past the tiles are not written.
+ * The GEMM between them: uavsal_conv_gemm with a = V, n_img = 16, H = Mp, W = 1, taps = 1, w = the sixteen
+ * transformed filter matrices (G g G^T)_k packed one after another, w_group_stride = their size in floats
+ * (packing.py 'f32wino').  Image strides are in pixels, 0 = H * W.
+ */
+typedef struct uavsal_wino_desc {
+    const float* in;   int32_t ldi;  int64_t in_img_stride;
+    float* out;        int32_t ldo;  int64_t out_img_stride;
+    int32_t n_img, H, W, C;
+    int64_t Mp;
+    const float* scale; const float* bias;
+    int32_t act, epi;
+    const float* res;   int32_t ldr;  int64_t res_img_stride;
+    const float* aux;   int32_t ldx;  int64_t aux_img_stride;
+    const float* hprev; int32_t ldh;  int64_t h_img_stride;
+} uavsal_wino_desc;
+
+int uavsal_wino_input(const uavsal_wino_desc* d, uavsal_stream_t stream);
+int uavsal_wino_output(const uavsal_wino_desc* d, uavsal_stream_t stream);
+
 /* Sum over groups of T consecutive images (model.py:357-358): out[b] = sum_t in[b*T+t]. */
 typedef struct uavsal_tsum_desc {
     const float* in;  int32_t ldi;
@@ -362,6 +395,8 @@ int uavsal_plan_add_dw(uavsal_plan* p, const uavsal_dw_desc* d);
 int uavsal_plan_add_stem(uavsal_plan* p, const uavsal_stem_desc* d);
 int uavsal_plan_add_bilinear(uavsal_plan* p, const uavsal_bilinear_desc* d);
 int uavsal_plan_add_tdiff(uavsal_plan* p, const uavsal_tdiff_desc* d);
+int uavsal_plan_add_wino_input(uavsal_plan* p, const uavsal_wino_desc* d);
+int uavsal_plan_add_wino_output(uavsal_plan* p, const uavsal_wino_desc* d);
 int uavsal_plan_add_tsum(uavsal_plan* p, const uavsal_tsum_desc* d);
 int uavsal_plan_add_layout(uavsal_plan* p, const uavsal_layout_desc* d);
 int uavsal_plan_add_copy(uavsal_plan* p, const uavsal_copy_desc* d);
@@ -403,7 +438,7 @@ int uavsal_plan_graph_launch(uavsal_plan* p, uavsal_stream_t stream);
 int uavsal_plan_time(uavsal_plan* p, int first, int last, int iters, uavsal_stream_t stream, float* ms);
 
 int uavsal_abi_version(void);
-int uavsal_sizeof_desc(int which); /* 0 conv,1 dw,2 stem,3 bilinear,4 tdiff,5 tsum,6 layout,7 post,8 guard,9 copy,10 fused_ir */
+int uavsal_sizeof_desc(int which); /* 0 conv,1 dw,2 stem,3 bilinear,4 tdiff,5 tsum,6 layout,7 post,8 guard,9 copy,10 fused_ir,11 wino */
 const char* uavsal_build_info(void);
 
 #ifdef __cplusplus

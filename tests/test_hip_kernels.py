@@ -186,6 +186,50 @@ def test_conv3x3(ops, prec, case):
     assert err <= TOL[prec] * 4.0, (case, prec, err)
 
 
+WINO_CASES = [
+    # n, h, w, cin, cout, act, res
+    (1, 12, 20, 64, 96, 1, False), (2, 9, 13, 448, 256, 1, False),      # odd sizes: half-empty last tile row / column
+    (1, 45, 80, 256, 256, 0, True), (3, 7, 5, 32, 40, 0, False), (2, 2, 3, 64, 64, 1, True), (8, 23, 40, 96, 128, 1, False)]
+
+
+@pytest.mark.parametrize("case", WINO_CASES)
+def test_conv3x3_winograd(ops, case):
+    """Dense 3x3 conv as Winograd F(2x2, 3x3): input transform + ONE GEMM launch over the sixteen planes (per-plane
+    weights) + output transform with BN / ReLU6 / residual, against F.conv2d on the CPU.  fp32 everywhere; the transforms
+    add a few roundings per value (coefficients 0, +-1, +-1/2), hence 2e-4 instead of 8e-5."""
+    n, h, w, cin, cout, act, use_res = case
+    x = rnd((n, cin, h, w), 70, 2.0)
+    wt = rnd((cout, cin, 3, 3), 71, 1.0 / np.sqrt(9 * cin))
+    scale = rnd((cout,), 72) * 0.5 + 1.0
+    bias = rnd((cout,), 73)
+    res = rnd((n, cout, h, w), 74) if use_res else None
+    ref = act_ref(F.conv2d(x, wt, padding=1) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1), act)
+    if use_res:
+        ref = ref + res
+    got = ops.conv3x3_winograd(nhwc(x), wt, scale, bias, act=act, res=nhwc(res) if use_res else None)
+    err = (nchw(got) - ref).abs().max().item()
+    direct = ops.conv_gemm(nhwc(x), wt, scale, bias, act=act, res=nhwc(res) if use_res else None, prec="f32")
+    print("winograd %s: max-abs vs F.conv2d %.2e (direct fp32 kernel: %.2e)" % (case, err, (nchw(direct) - ref).abs().max().item()))
+    assert err <= 2e-4, (case, err)
+    raw = ops.conv3x3_winograd(nhwc(x), wt)          # no BN (the hoisted W_x x_t of the ConvTWA layer)
+    assert (nchw(raw) - F.conv2d(x, wt, padding=1)).abs().max().item() <= 2e-4
+
+
+@pytest.mark.parametrize("shape", [(1, 45, 80), (2, 12, 20), (3, 9, 13)])
+def test_twa_step_winograd(ops, shape):
+    """ConvTWA step with the gate convolution through Winograd: the output transform applies sigmoid / convex update."""
+    n, h, w = shape
+    c = 256
+    x = rnd((n, c, h, w), 75, 2.0)
+    hp = rnd((n, c, h, w), 76, 2.0)
+    wt = rnd((c, 2 * c, 3, 3), 77, 1.0 / np.sqrt(9 * 2 * c))
+    gate = torch.sigmoid(F.conv2d(torch.cat([x, hp], 1), wt, padding=1))
+    ref = gate * x + (1 - gate) * hp
+    pre = ops.conv3x3_winograd(nhwc(x), wt[:, :c].contiguous())
+    got = ops.conv3x3_winograd(nhwc(hp), wt[:, c:].contiguous(), twa=(nhwc(x), pre))
+    assert (nchw(got) - ref).abs().max().item() <= 2e-4
+
+
 @pytest.mark.parametrize("prec", ["f32", "f16x3", "bf16x3"])
 def test_twa_step(ops, prec):
     """ConvTWACell.forward (model_convlstm.py:276-292) with the x half of the conv hoisted."""

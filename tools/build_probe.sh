@@ -6,7 +6,7 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 C=$R/iip_uavsal_saliency_amd/csrc
 mkdir -p $R/tools/_tmp
 FLAGS="-O3 --offload-arch=gfx950 -std=c++17 -fPIC -I$R/include -I$C"
-OTHERS="$C/conv_gemm.o $C/dw_conv.o $C/fused_ir.o $C/glue.o $C/post.o $C/plan.o"
+OTHERS="$C/conv_gemm.o $C/dw_conv.o $C/fused_ir.o $C/glue.o $C/post.o $C/plan.o $C/winograd.o"
 VARIANTS=${VARIANTS:-"probe:-DUAVSAL_PROBE stamps:-DUAVSAL_K32_STAMPS"}
 for v in $VARIANTS; do
   name=${v%%:*}; defs=$(echo ${v#*:} | tr ',' ' ')
