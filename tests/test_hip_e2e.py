@@ -123,6 +123,24 @@ def test_demo_default_call_at_full_size_vs_reference_golden(hip_model, golden_di
     assert all(e.streamk_clean() for e in hip_model._engines.values())
 
 
+def test_winograd_and_direct_3x3_agree_end_to_end(hip_model, golden_dir):
+    """Exact-fp32 mode with the dense 3x3 convs as Winograd F(2x2, 3x3) (default) and as implicit GEMMs: both within the
+    parity bound of the reference's own output at 360x640, and within 2e-4 of each other (oracle experiment: 5e-5)."""
+    g = np.load(os.path.join(golden_dir, "e2e_360x640_T8.npz"))
+    x, cb = make_inputs(8, 360, 640, int(g["seed"]))
+    outs = {}
+    try:
+        for wino in (True, False):
+            hip_model.winograd = wino
+            outs[wino], _ = _run_hip(hip_model, 8, "f32", x, cb)
+            err = np.abs(outs[wino].numpy() - g["out"]).max()
+            print("winograd=%s: map max-abs vs reference golden %.3e" % (wino, err))
+            assert err <= MAP_TOL["f32"], (wino, err)
+    finally:
+        hip_model.winograd = True
+    assert (outs[True] - outs[False]).abs().max().item() <= 2e-4
+
+
 def make_clips(C, T, H, W, seed=0, t0=0):
     """Clip c is seeded with seed + c (oracle/make_goldens.py clip_inputs, bench.py make_clips)."""
     h, w = H // 8, W // 8
@@ -221,6 +239,7 @@ def test_lost_streamk_piece_raises_and_poisons(hip_model):
     x, cb = make_inputs(T, H, W)
     args = (x.cuda(), [cb[0].cuda(), cb[1].cuda()], None)
     hip_model.time_dims, hip_model.precision = T, "f32"
+    hip_model.winograd = False                # the direct 3x3 convs are the stream-K launches (Winograd plans have none)
     good, _ = hip_model(*args)
     hip_model._sk_debug = (2000, -1)          # (poll limit, withhold every published flag)
     try:
@@ -245,9 +264,12 @@ def test_lost_streamk_piece_raises_and_poisons(hip_model):
     finally:
         hip_model._sk_debug = (0, 0)
         hip_model.sync_errors = None
-    again, _ = hip_model(*args)               # workspaces were re-zeroed: the healthy plan still works
-    assert torch.equal(again, good)
-    assert all(e.streamk_clean() for e in hip_model._engines.values())
+    try:
+        again, _ = hip_model(*args)               # workspaces were re-zeroed: the healthy plan still works
+        assert torch.equal(again, good)
+        assert all(e.streamk_clean() for e in hip_model._engines.values())
+    finally:
+        hip_model.winograd = True
 
 
 def test_bf16_single_pass_error_is_reported(hip_model, oracle):
