@@ -109,7 +109,7 @@ class WinoDesc(C.Structure):
     _fields_ = [("inp", _f), ("ldi", C.c_int32), ("in_img_stride", C.c_int64),
                 ("out", _f), ("ldo", C.c_int32), ("out_img_stride", C.c_int64),
                 ("n_img", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32),
-                ("Mp", C.c_int64),
+                ("Mp", C.c_int64), ("R", C.c_int32),
                 ("scale", _f), ("bias", _f), ("act", C.c_int32), ("epi", C.c_int32),
                 ("res", _f), ("ldr", C.c_int32), ("res_img_stride", C.c_int64),
                 ("aux", _f), ("ldx", C.c_int32), ("aux_img_stride", C.c_int64),

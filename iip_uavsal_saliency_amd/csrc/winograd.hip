@@ -1,4 +1,4 @@
-// Winograd F(2x2, 3x3) transforms for the path's dense 3x3 convolutions (stride 1, padding 1: conv_last of the SRF-Net
+// Winograd F(2x2, 3x3) and F(4x4, 3x3) transforms for the path's dense 3x3 convolutions (stride 1, padding 1: conv_last of the SRF-Net
 // head, reference model.py:155-156, and the ConvTWA gate convolution, model_convlstm.py:276-292), fp32 throughout.
 //
 //   out(2x2 tile) = A^T [ sum_c (G g G^T) .* (B^T d B) ] A        d = 4x4 input patch, g = 3x3 filter
@@ -10,8 +10,11 @@
 // for two memory-bound transform launches.  Numerics: coefficients 0, +-1, +-1/2 only; against direct fp32 convolution
 // the saliency map moves by 5e-5 (oracle experiment at 360x640, 8- and 20-frame calls: profiles/r3_winograd.md).
 //
-//   uavsal_wino_input : NHWC activation -> V[16][Mp][C],   V_k[tile][c] = (B^T d B)_k        one thread = (tile, 4 channels)
-//   uavsal_wino_output: M[16][Mp][C]    -> NHWC output,    y = A^T m A, then BN / ReLU6 / residual or the ConvTWA update
+//   uavsal_wino_input : NHWC activation -> V[P*P][Mp][C],  V_k[tile][c] = (B^T d B)_k        one thread = (tile, 4 channels)
+//   uavsal_wino_output: M[P*P][Mp][C]   -> NHWC output,    y = A^T m A, then BN / ReLU6 / residual or the ConvTWA update
+// uavsal_wino_desc.R = 2: 2x2 output tiles, P = 4, sixteen planes, 2.25x fewer multiplications than direct convolution;
+// R = 4: 4x4 output tiles, P = 6, thirty-six planes, 4x fewer (interpolation points 0, +-1, +-2: coefficients up to 8, a
+// single conv is ~20x less accurate than direct fp32 -- 2e-5 against 1e-6 at K = 576 -- the saliency map moves by 5.3e-5).
 // tile = (image, ty, tx) in row-major order; planes are Mp rows apart (Mp % 128 == 0: every plane is whole GEMM tiles;
 // rows past the tiles are never written -- the caller zero-fills the V buffer once -- and never read back).
 #include "common.h"
@@ -28,7 +31,41 @@ struct WinoK {
     long long total;
 };
 
+// one-dimensional transforms (applied to rows, then to columns)
+template <int R> struct WinoT;
+template <> struct WinoT<2> {
+    static constexpr int P = 4;
+    __device__ static __forceinline__ void bt(const f32x4 (&d)[4], f32x4 (&t)[4]) {      // B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
+        t[0] = d[0] - d[2]; t[1] = d[1] + d[2]; t[2] = d[2] - d[1]; t[3] = d[1] - d[3];
+    }
+    __device__ static __forceinline__ void at(const f32x4 (&m)[4], f32x4 (&y)[2]) {      // A^T = [1 1 1 0; 0 1 -1 -1]
+        y[0] = m[0] + m[1] + m[2]; y[1] = m[1] - m[2] - m[3];
+    }
+};
+template <> struct WinoT<4> {
+    static constexpr int P = 6;
+    __device__ static __forceinline__ void bt(const f32x4 (&d)[6], f32x4 (&t)[6]) {
+        // B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+        t[0] = 4.f * d[0] - 5.f * d[2] + d[4];
+        t[1] = (d[3] + d[4]) - 4.f * (d[1] + d[2]);
+        t[2] = 4.f * (d[1] - d[2]) + (d[4] - d[3]);
+        t[3] = 2.f * (d[3] - d[1]) + (d[4] - d[2]);
+        t[4] = 2.f * (d[1] - d[3]) + (d[4] - d[2]);
+        t[5] = 4.f * d[1] - 5.f * d[3] + d[5];
+    }
+    __device__ static __forceinline__ void at(const f32x4 (&m)[6], f32x4 (&y)[4]) {
+        // A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+        const f32x4 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+        y[0] = m[0] + s12 + s34;
+        y[1] = d12 + 2.f * d34;
+        y[2] = s12 + 4.f * s34;
+        y[3] = d12 + 8.f * d34 + m[5];
+    }
+};
+
+template <int R>
 __global__ __launch_bounds__(256) void wino_input_kernel(const WinoK p) {
+    constexpr int P = WinoT<R>::P;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= p.total) return;
     const int c4 = (int)(idx % p.C4);
@@ -37,37 +74,32 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const WinoK p) {
     const int n = (int)(tile / tpi);
     const int r = (int)(tile - (long long)n * tpi);
     const int tyi = r / p.tx, txi = r - tyi * p.tx;
-    const int y0 = 2 * tyi - 1, x0 = 2 * txi - 1;
+    const int y0 = R * tyi - 1, x0 = R * txi - 1;
     const float* base = p.in + (size_t)n * p.in_is * p.ldi + c4 * 4;
-    f32x4 d[4][4];
+    f32x4 t[P][P];                                       // t[i][j] = (B^T d)[i][j], built column by column
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int y = y0 + i;
+    for (int j = 0; j < P; ++j) {
+        const int x = x0 + j;
+        f32x4 col[P], tc[P];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int x = x0 + j;
-            d[i][j] = (y >= 0 && y < p.H && x >= 0 && x < p.W)
-                          ? *reinterpret_cast<const f32x4*>(base + ((size_t)y * p.W + x) * p.ldi)
-                          : (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < P; ++i) {
+            const int y = y0 + i;
+            col[i] = (y >= 0 && y < p.H && x >= 0 && x < p.W)
+                         ? *reinterpret_cast<const f32x4*>(base + ((size_t)y * p.W + x) * p.ldi)
+                         : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-    }
-    // B^T d (rows), then (.) B (columns):  B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
-    f32x4 t[4][4];
+        WinoT<R>::bt(col, tc);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        t[0][j] = d[0][j] - d[2][j];
-        t[1][j] = d[1][j] + d[2][j];
-        t[2][j] = d[2][j] - d[1][j];
-        t[3][j] = d[1][j] - d[3][j];
+        for (int i = 0; i < P; ++i) t[i][j] = tc[i];
     }
     float* o = p.out + (size_t)tile * p.ldo + c4 * 4;
     const size_t plane = (size_t)p.Mp * p.ldo;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        *reinterpret_cast<f32x4*>(o + (size_t)(4 * i + 0) * plane) = t[i][0] - t[i][2];
-        *reinterpret_cast<f32x4*>(o + (size_t)(4 * i + 1) * plane) = t[i][1] + t[i][2];
-        *reinterpret_cast<f32x4*>(o + (size_t)(4 * i + 2) * plane) = t[i][2] - t[i][1];
-        *reinterpret_cast<f32x4*>(o + (size_t)(4 * i + 3) * plane) = t[i][1] - t[i][3];
+    for (int i = 0; i < P; ++i) {                        // (.) B = the same transform along the row
+        f32x4 v[P];
+        WinoT<R>::bt(t[i], v);
+#pragma unroll
+        for (int j = 0; j < P; ++j) *reinterpret_cast<f32x4*>(o + (size_t)(P * i + j) * plane) = v[j];
     }
 }
 
@@ -78,7 +110,9 @@ __device__ __forceinline__ f32x4 sigmoid4(f32x4 z) {
     return g;
 }
 
+template <int R>
 __global__ __launch_bounds__(256) void wino_output_kernel(const WinoK p) {
+    constexpr int P = WinoT<R>::P;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= p.total) return;
     const int c4 = (int)(idx % p.C4);
@@ -89,24 +123,19 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const WinoK p) {
     const int tyi = r / p.tx, txi = r - tyi * p.tx;
     const float* mi = p.in + (size_t)tile * p.ldi + c4 * 4;
     const size_t plane = (size_t)p.Mp * p.ldi;
-    f32x4 m[4][4];
+    f32x4 s[R][P];                                       // s = A^T m, built column by column
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < P; ++j) {
+        f32x4 col[P], sc_[R];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) m[i][j] = *reinterpret_cast<const f32x4*>(mi + (size_t)(4 * i + j) * plane);
-    // A^T m (rows), then (.) A (columns):  A^T = [1 1 1 0; 0 1 -1 -1]
-    f32x4 s[2][4];
+        for (int i = 0; i < P; ++i) col[i] = *reinterpret_cast<const f32x4*>(mi + (size_t)(P * i + j) * plane);
+        WinoT<R>::at(col, sc_);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        s[0][j] = m[0][j] + m[1][j] + m[2][j];
-        s[1][j] = m[1][j] - m[2][j] - m[3][j];
+        for (int a = 0; a < R; ++a) s[a][j] = sc_[a];
     }
-    f32x4 y[2][2];
+    f32x4 y[R][R];
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-        y[a][0] = s[a][0] + s[a][1] + s[a][2];
-        y[a][1] = s[a][1] - s[a][2] - s[a][3];
-    }
+    for (int a = 0; a < R; ++a) WinoT<R>::at(s[a], y[a]);
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
     if (p.scale) {
         sc = *reinterpret_cast<const f32x4*>(p.scale + c4 * 4);
@@ -114,10 +143,10 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const WinoK p) {
     }
     const float lo = p.act == UAVSAL_ACT_RELU6 ? 0.f : -3.0e38f, hi = p.act == UAVSAL_ACT_RELU6 ? 6.f : 3.0e38f;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < R; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int yy = 2 * tyi + a, xx = 2 * txi + b;
+        for (int b = 0; b < R; ++b) {
+            const int yy = R * tyi + a, xx = R * txi + b;
             if (yy >= p.H || xx >= p.W) continue;
             const size_t pix = (size_t)yy * p.W + xx;
             f32x4 v = y[a][b];
@@ -141,7 +170,8 @@ int fill(const uavsal_wino_desc* d, WinoK& k, bool input) {
     if (d->n_img <= 0 || d->H <= 0 || d->W <= 0 || d->C <= 0) return UAVSAL_EINVAL;
     if ((d->C & 3) || (d->ldi & 3) || (d->ldo & 3) || d->ldi < d->C || d->ldo < d->C) return UAVSAL_EALIGN;
     if (!uavsal_aligned16(d->in) || !uavsal_aligned16(d->out)) return UAVSAL_EALIGN;
-    k.ty = (d->H + 1) / 2; k.tx = (d->W + 1) / 2;
+    if (d->R != 2 && d->R != 4) return UAVSAL_ESHAPE;
+    k.ty = (d->H + d->R - 1) / d->R; k.tx = (d->W + d->R - 1) / d->R;
     const long long tiles = (long long)d->n_img * k.ty * k.tx;
     if ((d->Mp & 127) || d->Mp < tiles) return UAVSAL_ESHAPE;
     k.in = d->in; k.out = d->out; k.ldi = d->ldi; k.ldo = d->ldo; k.Mp = d->Mp;
@@ -180,7 +210,8 @@ extern "C" int uavsal_wino_input(const uavsal_wino_desc* d, uavsal_stream_t stre
     WinoK k;
     const int e = fill(d, k, true);
     if (e) return e;
-    hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((k.total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, k);
+    if (d->R == 4) hipLaunchKernelGGL(wino_input_kernel<4>, dim3((unsigned)((k.total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, k);
+    else hipLaunchKernelGGL(wino_input_kernel<2>, dim3((unsigned)((k.total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, k);
     return uavsal_launch_status();
 }
 
@@ -188,6 +219,7 @@ extern "C" int uavsal_wino_output(const uavsal_wino_desc* d, uavsal_stream_t str
     WinoK k;
     const int e = fill(d, k, false);
     if (e) return e;
-    hipLaunchKernelGGL(wino_output_kernel, dim3((unsigned)((k.total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, k);
+    if (d->R == 4) hipLaunchKernelGGL(wino_output_kernel<4>, dim3((unsigned)((k.total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, k);
+    else hipLaunchKernelGGL(wino_output_kernel<2>, dim3((unsigned)((k.total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, k);
     return uavsal_launch_status();
 }

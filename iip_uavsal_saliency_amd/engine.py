@@ -119,6 +119,9 @@ class Engine:
         # convolutions of the recurrence too, with that GEMM tile)
         self.winograd = precision == "f32" and bool(getattr(model, "winograd", True)) and os.environ.get("UAVSAL_WINOGRAD", "1") != "0"
         self.winograd_steps = int(os.environ.get("UAVSAL_WINOGRAD_STEPS", "8"))
+        # output tile of the transforms: 2 = F(2x2, 3x3), 4 = F(4x4, 3x3); for the all-frames convs / for the recurrence steps
+        self.winograd_r = int(os.environ.get("UAVSAL_WINOGRAD_R", "2"))
+        self.winograd_step_r = int(os.environ.get("UAVSAL_WINOGRAD_STEP_R", "2"))
         self.fuse_blocks = bool(getattr(model, "fuse_blocks", True))
         self._split_want = set()
         self._no_shadow = set()
@@ -402,40 +405,41 @@ class Engine:
         self.ops_meta[-1]["dwproj"] = dwproj
         self._add(self.lib.uavsal_plan_add_conv, d, "plan_add_conv(%s)" % name)
 
-    def conv3_wino(self, name, a: V, conv, bn, out: V, act, wslice=None, n_img=None, strides=None, twa=None, gemm_tile=0):
-        """Dense 3x3 conv (stride 1, padding 1) as Winograd F(2x2, 3x3), exact-fp32 mode only: input transform, ONE GEMM
-        launch over the sixteen transform planes (per-plane weights), output transform with the epilogue -- 2.25x fewer
-        MFMA FLOPs than the implicit GEMM (csrc/winograd.hip).  `twa=(x_t, pre_t)`: ConvTWA update in the output transform."""
+    def conv3_wino(self, name, a: V, conv, bn, out: V, act, wslice=None, n_img=None, strides=None, twa=None, gemm_tile=0, r=2):
+        """Dense 3x3 conv (stride 1, padding 1) as Winograd F(r x r, 3x3), exact-fp32 mode only: input transform, ONE GEMM
+        launch over the (r + 2)^2 transform planes (per-plane weights), output transform with the epilogue -- 2.25x (r = 2)
+        or 4x (r = 4) fewer MFMA FLOPs than the implicit GEMM (csrc/winograd.hip).  `twa=(x_t, pre_t)`: ConvTWA update in the output transform."""
         cin, cout = a.c, out.c
         n = a.n if n_img is None else n_img
         hw = a.h * a.w
-        tiles = n * ((a.h + 1) // 2) * ((a.w + 1) // 2)
+        tiles = n * ((a.h + r - 1) // r) * ((a.w + r - 1) // r)
+        pp = (r + 2) * (r + 2)
         mp = P.roundup(tiles, 128)
         st = strides or {}
-        v = self._scr("WV", 16, mp, 1, cin)
-        mm = self._scr("WM", 16, mp, 1, cout)
-        self._meta(kind="wino_in", name=name + ".xin", flops=0.0, bytes=4.0 * (n * hw * cin + 16.0 * tiles * cin))
+        v = self._scr("WV", pp, mp, 1, cin)
+        mm = self._scr("WM", pp, mp, 1, cout)
+        self._meta(kind="wino_in", name=name + ".xin", flops=0.0, bytes=4.0 * (n * hw * cin + float(pp) * tiles * cin))
         if not self._dry:
             wi = L.WinoDesc()
             wi.inp, wi.ldi, wi.in_img_stride = a.ptr, a.ld, st.get("a", hw)
             wi.out, wi.ldo = v.ptr, cin
-            wi.n_img, wi.H, wi.W, wi.C, wi.Mp = n, a.h, a.w, cin, mp
+            wi.n_img, wi.H, wi.W, wi.C, wi.Mp, wi.R = n, a.h, a.w, cin, mp, r
             self._add(self.lib.uavsal_plan_add_wino_input, wi, "plan_add_wino_input(%s)" % name)
-        self._meta(kind="conv1", name=name, flops=2.0 * 16 * tiles * cin * cout,
-                   bytes=4.0 * 16 * (tiles * (cin + cout) + cin * cout), M=16 * mp, K=cin, Nc=cout,
+        self._meta(kind="conv1", name=name, flops=2.0 * pp * tiles * cin * cout,
+                   bytes=4.0 * pp * (tiles * (cin + cout) + cin * cout), M=pp * mp, K=cin, Nc=cout,
                    direct_flops=2.0 * n * hw * cin * cout * 9)
         if not self._dry:
-            key = ("wino", id(conv), wslice)
+            key = ("wino", id(conv), wslice, r)
             if key not in self._wcache:
                 w = conv.weight.detach()
                 if wslice is not None:
                     w = w[:, wslice[0]:wslice[1]]
-                self._wcache[key] = self._dev(P.pack_wino_weight(w))
+                self._wcache[key] = self._dev(P.pack_wino_weight(w, r))
             d = L.ConvDesc()
             d.a, d.lda, d.a_img_stride = v.ptr, cin, mp
             d.w, d.w_group_stride = self._wcache[key].data_ptr(), P.roundup(cout, 32) * P.roundup(cin, 32)
             d.out, d.ldc, d.o_img_stride = mm.ptr, cout, mp
-            d.n_img, d.H, d.W, d.Cin, d.Cout, d.taps = 16, mp, 1, cin, cout, 1
+            d.n_img, d.H, d.W, d.Cin, d.Cout, d.taps = pp, mp, 1, cin, cout, 1
             d.prec, d.act, d.epi, d.tile = self.prec, L.ACT_NONE, L.EPI_AFFINE, gemm_tile
             d.err = self._err
             self.ops_meta[-1]["split"] = False
@@ -443,14 +447,14 @@ class Engine:
             self.ops_meta[-1]["streamk"] = 0
             self.ops_meta[-1]["dwproj"] = 0
             self._add(self.lib.uavsal_plan_add_conv, d, "plan_add_conv(%s)" % name)
-        self._meta(kind="wino_out", name=name + ".xout", flops=0.0, bytes=4.0 * (16.0 * tiles * cout + n * hw * cout))
+        self._meta(kind="wino_out", name=name + ".xout", flops=0.0, bytes=4.0 * (float(pp) * tiles * cout + n * hw * cout))
         if out.key is not None and self._dry:
             self._no_shadow.add(out.key)            # the output transform does not write split shadows
         if not self._dry:
             wo = L.WinoDesc()
             wo.inp, wo.ldi = mm.ptr, cout
             wo.out, wo.ldo, wo.out_img_stride = out.ptr, out.ld, st.get("o", hw)
-            wo.n_img, wo.H, wo.W, wo.C, wo.Mp = n, a.h, a.w, cout, mp
+            wo.n_img, wo.H, wo.W, wo.C, wo.Mp, wo.R = n, a.h, a.w, cout, mp, r
             if bn is not None:
                 s_, b_ = self._affine(bn, cout)
                 wo.scale, wo.bias = s_.data_ptr(), b_.data_ptr()
@@ -741,7 +745,7 @@ class Engine:
         self.join(6)
         x = self._buf("sfnet", N, h, w, 256)
         if self.winograd:
-            self.conv3_wino("conv_last", cat, sf.conv_last[0], sf.conv_last[1], x, R6)
+            self.conv3_wino("conv_last", cat, sf.conv_last[0], sf.conv_last[1], x, R6, r=self.winograd_r)
         else:
             self.conv("conv_last", cat, sf.conv_last[0], sf.conv_last[1], x, R6, taps=9)
         self._mark("srf_head", s0)
@@ -837,7 +841,7 @@ class Engine:
         else:
             pre = self._buf("twa_pre", N, h, w, 256)
             if self.winograd:
-                self.conv3_wino("twa.wx", xf, rc, None, pre, NONE, wslice=(0, 256))
+                self.conv3_wino("twa.wx", xf, rc, None, pre, NONE, wslice=(0, 256), r=self.winograd_r)
             else:
                 self.conv("twa.wx", xf, rc, None, pre, NONE, taps=9, wslice=(0, 256))    # W[:, :256] * x_t, all t
         for t in range(0 if lstm else Lq):
@@ -847,7 +851,7 @@ class Engine:
             if self.winograd and self.winograd_steps:
                 self.conv3_wino("twa.step%d" % t, a, rc, None, ro.frames(t, self.n_seq), NONE, wslice=(256, 512),
                                 n_img=self.n_seq, strides=strides, twa=(xf.frames(t, self.n_seq), pre.frames(t, self.n_seq)),
-                                gemm_tile=self.winograd_steps)
+                                gemm_tile=self.winograd_steps, r=self.winograd_step_r)
                 continue
             self.conv("twa.step%d" % t, a, rc, None, ro.frames(t, self.n_seq), NONE, taps=9, wslice=(256, 512),
                       epi=L.EPI_TWA, res=xf.frames(t, self.n_seq), aux=pre.frames(t, self.n_seq),

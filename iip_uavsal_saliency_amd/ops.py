@@ -134,36 +134,37 @@ def conv_gemm(x, weight, scale=None, bias=None, act=L.ACT_NONE, res=None, out=No
     return (out, shadow) if split_out else out
 
 
-def conv3x3_winograd(x, weight, scale=None, bias=None, act=L.ACT_NONE, res=None, twa=None):
-    """Dense 3x3 conv (stride 1, padding 1) through Winograd F(2x2, 3x3), fp32: input transform, ONE GEMM launch over the
-    sixteen transform planes (per-plane weights), output transform with the epilogue.  `twa=(x_t, pre_t)`: `x` is
+def conv3x3_winograd(x, weight, scale=None, bias=None, act=L.ACT_NONE, res=None, twa=None, r=2):
+    """Dense 3x3 conv (stride 1, padding 1) through Winograd F(r x r, 3x3), r = 2 or 4, fp32: input transform, ONE GEMM
+    launch over the (r + 2)^2 transform planes (per-plane weights), output transform with the epilogue.  `twa=(x_t, pre_t)`: `x` is
     h_{t-1} and the output transform applies the ConvTWA update (model_convlstm.py:276-292)."""
     lib = L.load()
     ip, ldi, n, h, w, cin = _nhwc_view(x)
     cout = weight.shape[0]
-    tiles = n * ((h + 1) // 2) * ((w + 1) // 2)
+    tiles = n * ((h + r - 1) // r) * ((w + r - 1) // r)
+    pp = (r + 2) * (r + 2)
     mp = P.roundup(tiles, 128)
     dev = x.device
-    v = torch.zeros((16, mp, cin), dtype=torch.float32, device=dev)
-    m = torch.empty((16, mp, cout), dtype=torch.float32, device=dev)
+    v = torch.zeros((pp, mp, cin), dtype=torch.float32, device=dev)
+    m = torch.empty((pp, mp, cout), dtype=torch.float32, device=dev)
     out = torch.empty((n, h, w, cout), dtype=torch.float32, device=dev)
-    wp = P.pack_wino_weight(weight).to(dev)
+    wp = P.pack_wino_weight(weight, r).to(dev)
     st = _stream(x)
     wi = L.WinoDesc()
     wi.inp, wi.ldi, wi.out, wi.ldo = ip, ldi, v.data_ptr(), cin
-    wi.n_img, wi.H, wi.W, wi.C, wi.Mp = n, h, w, cin, mp
+    wi.n_img, wi.H, wi.W, wi.C, wi.Mp, wi.R = n, h, w, cin, mp, r
     L.check(lib.uavsal_wino_input(C.byref(wi), st), "uavsal_wino_input")
     d = L.ConvDesc()
     d.a, d.lda, d.a_img_stride = v.data_ptr(), cin, mp
     d.w = wp.data_ptr()
     d.w_group_stride = P.roundup(cout, 32) * P.roundup(cin, 32)
     d.out, d.ldc, d.o_img_stride = m.data_ptr(), cout, mp
-    d.n_img, d.H, d.W, d.Cin, d.Cout, d.taps = 16, mp, 1, cin, cout, 1
+    d.n_img, d.H, d.W, d.Cin, d.Cout, d.taps = pp, mp, 1, cin, cout, 1
     d.prec, d.act, d.epi, d.tile = L.PREC["f32"], L.ACT_NONE, L.EPI_AFFINE, 0
     L.check(lib.uavsal_conv_gemm(C.byref(d), st), "uavsal_conv_gemm(winograd planes)")
     wo = L.WinoDesc()
     wo.inp, wo.ldi, wo.out, wo.ldo = m.data_ptr(), cout, out.data_ptr(), cout
-    wo.n_img, wo.H, wo.W, wo.C, wo.Mp = n, h, w, cout, mp
+    wo.n_img, wo.H, wo.W, wo.C, wo.Mp, wo.R = n, h, w, cout, mp, r
     keep = [v, m, wp]
     if scale is not None:
         npad = P.roundup(cout, 32)

@@ -86,17 +86,24 @@ def pack_conv_weight(w: torch.Tensor, prec: str) -> torch.Tensor:
     return torch.stack([hi, lo], 0).permute(2, 0, 1, 3).contiguous().view(torch.uint8).reshape(-1)
 
 
-def pack_wino_weight(w: torch.Tensor) -> torch.Tensor:
-    """Dense 3x3 `w` [Cout, Cin, 3, 3] -> the sixteen Winograd F(2x2, 3x3) filter matrices U_k = (G g G^T)_k, k = 4 i + j,
-    each packed like an fp32 1x1 weight [Npad][Kpad] (Kpad = Cin rounded up to 32), one after another: fp32 [16][Npad][Kpad]
-    as a flat byte tensor ('f32wino'; uavsal_conv_desc.w_group_stride = Npad * Kpad).  Transformed in fp64, rounded once."""
+_WINO_G = {2: [[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]],
+           4: [[1 / 4, 0.0, 0.0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6],
+               [1 / 24, -1 / 12, 1 / 6], [0.0, 0.0, 1.0]]}
+
+
+def pack_wino_weight(w: torch.Tensor, r: int = 2) -> torch.Tensor:
+    """Dense 3x3 `w` [Cout, Cin, 3, 3] -> the P*P (P = r + 2) Winograd F(r x r, 3x3) filter matrices U_k = (G g G^T)_k,
+    k = P i + j, each packed like an fp32 1x1 weight [Npad][Kpad] (Kpad = Cin rounded up to 32), one after another:
+    fp32 [P*P][Npad][Kpad] as a flat byte tensor (uavsal_conv_desc.w_group_stride = Npad * Kpad).  Transformed in
+    fp64, rounded once."""
     w = w.detach().double().cpu()
     cout, cin, kh, kw = w.shape
-    assert kh == 3 and kw == 3
-    g = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64)
-    u = torch.einsum("ij,ocjk,lk->iloc", g, w, g).reshape(16, cout, cin)          # [k][o][c]
+    assert kh == 3 and kw == 3 and r in _WINO_G
+    g = torch.tensor(_WINO_G[r], dtype=torch.float64)
+    pp = (r + 2) * (r + 2)
+    u = torch.einsum("ij,ocjk,lk->iloc", g, w, g).reshape(pp, cout, cin)          # [k][o][c]
     kpad, npad = roundup(cin, 32), roundup(cout, 32)
-    m = torch.zeros(16, npad, kpad, dtype=torch.float32)
+    m = torch.zeros(pp, npad, kpad, dtype=torch.float32)
     m[:, :cout, :cin] = u.float()
     return m.contiguous().view(torch.uint8).reshape(-1)
 

@@ -294,23 +294,25 @@ typedef struct uavsal_tdiff_desc {
 int uavsal_tdiff(const uavsal_tdiff_desc* d, uavsal_stream_t stream);
 
 /*
- * Winograd F(2x2, 3x3) transforms of a dense 3x3 convolution with stride 1 and padding 1 (csrc/winograd.hip), fp32.
- *   uavsal_wino_input : `in` NHWC [n_img, H, W, C] (row stride ldi)  ->  `out` = V[16][Mp][ldo]: plane k = 4 i + j holds
- *                       (B^T d B)_{ij} of every 2x2 output tile (tile = (image, ty, tx), row-major), channels C.
- *   uavsal_wino_output: `in` = M[16][Mp][ldi] (the sixteen GEMM results, channels C = Cout)  ->  `out` NHWC
+ * Winograd F(R x R, 3x3) transforms (R = 2 or 4, P = R + 2) of a dense 3x3 convolution with stride 1 and padding 1
+ * (csrc/winograd.hip), fp32.
+ *   uavsal_wino_input : `in` NHWC [n_img, H, W, C] (row stride ldi)  ->  `out` = V[P*P][Mp][ldo]: plane k = P i + j holds
+ *                       (B^T d B)_{ij} of every R x R output tile (tile = (image, ty, tx), row-major), channels C.
+ *   uavsal_wino_output: `in` = M[P*P][Mp][ldi] (the P*P GEMM results, channels C = Cout)  ->  `out` NHWC
  *                       [n_img, H, W, C]: y = A^T m A, then scale / bias (or NULL), ACT_NONE / ACT_RELU6, optional residual
  *                       (EPI_AFFINE), or the ConvTWA update h_t = g x_t + (1 - g) h_{t-1}, g = sigmoid(y + aux) with
  *                       res = x_t, hprev = h_{t-1} (EPI_TWA).
- * Mp (rows per plane) >= n_img * ceil(H/2) * ceil(W/2), a multiple of 128; rows past the tiles are not written.
- * The GEMM between them: uavsal_conv_gemm with a = V, n_img = 16, H = Mp, W = 1, taps = 1, w = the sixteen
+ * Mp (rows per plane) >= n_img * ceil(H/R) * ceil(W/R), a multiple of 128; rows past the tiles are not written.
+ * The GEMM between them: uavsal_conv_gemm with a = V, n_img = P*P, H = Mp, W = 1, taps = 1, w = the P*P
  * transformed filter matrices (G g G^T)_k packed one after another, w_group_stride = their size in floats
- * (packing.py 'f32wino').  Image strides are in pixels, 0 = H * W.
+ * (packing.pack_wino_weight).  Image strides are in pixels, 0 = H * W.
  */
 typedef struct uavsal_wino_desc {
     const float* in;   int32_t ldi;  int64_t in_img_stride;
     float* out;        int32_t ldo;  int64_t out_img_stride;
     int32_t n_img, H, W, C;
     int64_t Mp;
+    int32_t R;                   /* output tile: 2 = F(2x2, 3x3), 16 planes; 4 = F(4x4, 3x3), 36 planes */
     const float* scale; const float* bias;
     int32_t act, epi;
     const float* res;   int32_t ldr;  int64_t res_img_stride;
