@@ -120,7 +120,7 @@ class Engine:
         self.winograd = precision == "f32" and bool(getattr(model, "winograd", True)) and os.environ.get("UAVSAL_WINOGRAD", "1") != "0"
         self.winograd_steps = int(os.environ.get("UAVSAL_WINOGRAD_STEPS", "8"))
         # output tile of the transforms: 2 = F(2x2, 3x3), 4 = F(4x4, 3x3); for the all-frames convs / for the recurrence steps
-        self.winograd_r = int(os.environ.get("UAVSAL_WINOGRAD_R", "2"))
+        self.winograd_r = int(os.environ.get("UAVSAL_WINOGRAD_R", "4"))
         self.winograd_step_r = int(os.environ.get("UAVSAL_WINOGRAD_STEP_R", "2"))
         self.fuse_blocks = bool(getattr(model, "fuse_blocks", True))
         self._split_want = set()

@@ -168,7 +168,7 @@ class UAVSal(nn.Module):
         self.stream_k = True            # fp32 GEMMs: split K across workgroups when whole tiles leave CUs idle
         self.presplit = True            # f16x3: producers also write hi/lo fp16 shadows, GEMMs stage them by LDS-DMA
         self.fuse_blocks = True         # features[1..7]: whole inverted-residual block in one launch (uavsal_fused_ir)
-        self.winograd = True            # exact-fp32 mode: dense 3x3 convs as Winograd F(2x2, 3x3) (csrc/winograd.hip)
+        self.winograd = True            # exact-fp32 mode: dense 3x3 convs as Winograd F(4x4 / 2x2, 3x3) (csrc/winograd.hip)
         # A device-side error (a stream-K hand-off that timed out) always NaN-fills the returned map and state.
         # True: the call also waits for its own launches (one event wait) and raises before returning;
         # False: fully asynchronous, the RuntimeError comes from the next call / `check_errors()`.
