@@ -102,7 +102,7 @@ class FusedIrDesc(C.Structure):
                 ("wd", _f), ("scale_d", _f), ("bias_d", _f), ("w2", _f), ("scale2", _f), ("bias2", _f),
                 ("res", _f), ("ldr", C.c_int32), ("out", _f), ("ldo", C.c_int32),
                 ("n_img", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32),
-                ("hidden", C.c_int32), ("Cout", C.c_int32), ("stride", C.c_int32)]
+                ("hidden", C.c_int32), ("Cout", C.c_int32), ("stride", C.c_int32), ("tile", C.c_int32)]
 
 
 class WinoDesc(C.Structure):
@@ -189,7 +189,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.uavsal_abi_version() != 13:
+    if lib.uavsal_abi_version() != 14:
         raise RuntimeError("libuavsal_hip.so ABI version mismatch")
     for i, t in enumerate(DESC_TYPES):
         if lib.uavsal_sizeof_desc(i) != C.sizeof(t):

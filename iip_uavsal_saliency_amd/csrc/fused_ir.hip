@@ -4,19 +4,26 @@
 // tensors E and D never reach HBM: at 360x640 the unfused features.2 block moves 482 MB (E alone is 177 MB
 // written + 177 MB read) for 40 MB of block input + output.
 //
-// One 256-thread workgroup produces an 8x8 patch of output pixels of one image.  The input patch with its
-// halo ((8-1)*S+3 squared pixels) is staged once in LDS; the hidden channels are processed in chunks of HC:
-//   expand : E[halo pixel][c] = x . W1 on v_mfma_f32_16x16x4_f32 (exact fp32, the vector-FMA rate, but the
-//            weights are B fragments held in VGPRs: the first version of this kernel used scalar-operand
-//            v_fmac and spent its time waiting for s_load -- it was slower than the three separate launches).
-//            A = x from LDS (one ds_read_b32 per MFMA), 16-pixel row tiles dealt round-robin to the 4 waves;
-//            relu6(bn1) and EXACT ZERO outside the image (the depthwise conv pads E, not x) -> LDS, channel-major;
-//   dw     : lane = (channel, pixel group): nine taps from LDS, tap weights / BN in VGPRs, relu6(bn2) -> D (LDS);
-//   project: wave w owns output pixels 16w..16w+15: OUT += D . W2 on the same MFMA, accumulators live across
-//            the chunks (4 VGPRs per 16 output channels);
-// epilogue : bn3, optional residual (the block input at the same pixel), 64-byte stores.
-// MFMA lane maps (cdna_hip_programming.md): A[l & 15][k = l >> 4], B[k = l >> 4][l & 15],
-// D[row = 4 * (l >> 4) + reg][col = l & 15].
+// One 256-thread workgroup produces a TY x TX patch of output pixels of one image (8x8 when the launch has few patches,
+// 16x16 / 8x16 otherwise: each wave then owns PT = 4 / 2 tiles of 16 pixels and every weight fragment it loads is used
+// that many times).  The hidden channels are processed in chunks of HC:
+//   expand : E^T[channel][halo pixel] = W1^T . x^T on v_mfma_f32_16x16x4_f32 (exact fp32).  B = x read ONCE from global
+//            memory straight into the fragment registers (lane = (halo pixel, channel group): KE contiguous channels) and
+//            kept for all chunks; A = W1^T in VGPRs.  The accumulator lane holds 4 consecutive hidden channels of one
+//            pixel: relu6(bn1), EXACT ZERO outside the image (the depthwise conv pads E, not x), one ds_write_b128 into
+//            E[pixel][HC + 4] (pixel-major, 16-byte pad: consecutive pixels land on different bank groups; for stride 2
+//            the halo columns are stored even columns first, then odd, so that a tap reads consecutive slots);
+//   dw     : lane = (output pixel l & 15, channel group l >> 4 of HC/4 channels): nine taps x HC/16 ds_read_b128, tap
+//            weights / BN in VGPRs, relu6(bn2) -- and the lane's values ARE its B fragment of the projection MFMA
+//            (k index (l >> 4, s) <-> channel (l >> 4) * HC/4 + s), so D never goes through LDS;
+//   project: OUT^T[cout][pixel] += W2^T . D^T on the same MFMA, accumulators live across the chunks; the lane ends with 4
+//            consecutive output channels of one pixel: bn3, optional residual, one 16-byte store.
+// Two buffers of E when they fit (one barrier per chunk), else one (two barriers).
+// The first version of this kernel (round 2) kept E channel-major with scalar LDS accesses (4-way bank conflicts on
+// both sides), sent D through LDS, reloaded every weight fragment per 16 output pixels and staged x in LDS:
+// profiles/r3_fused_ir.md has the before / after.
+// MFMA lane maps (cdna_hip_programming.md): A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15],
+// D[i = 4 * (l >> 4) + reg][j = l & 15].
 // This kernel is used for every GEMM precision mode: it is exact fp32 and the blocks it covers are
 // bandwidth-bound (4 GMAC per clip in total).
 #include "common.h"
@@ -31,26 +38,51 @@ struct FusedK {
     int ldi, ldr, ldo, H, W, Ho, Wo, tiles_x, tiles_y;
 };
 
-template <int CIN, int HID, int COUT, int S, bool EXPAND, int HC>
-__global__ __launch_bounds__(256) void fused_ir_kernel(const FusedK p) {
-    constexpr int TY = 8, TX = 8;
-    constexpr int IH = (TY - 1) * S + 3, IW = (TX - 1) * S + 3, NIN = IH * IW;
-    constexpr int NRT = (NIN + 15) / 16, NINP = NRT * 16;       // halo pixels in row tiles of 16
-    constexpr int ESTR = NINP + 1;                              // 17 mod 32: lanes = 16 channels hit 16 banks
-    constexpr int DSTR = 81;
-    constexpr int NCH = HID / HC;
-    constexpr int NCTE = HC / 16;                               // column tiles of the expand GEMM
-    constexpr int NCT = (COUT + 15) / 16;                       // column tiles of the projection GEMM
-    constexpr int KE = CIN / 4, KP = HC / 4;                    // MFMA k steps
-    constexpr int NJOB = HC / 16, NPART = 4 / NJOB;             // depthwise: channel blocks x pixel parts over the waves
-    constexpr int PXL = 64 / (4 * NPART);                       // output pixels per lane in the depthwise phase
-    static_assert(HID % HC == 0 && HC % 16 == 0 && CIN % 4 == 0 && COUT % 8 == 0, "channel blocking");
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x4 relu6_4(f32x4 v) {
+    return (f32x4){__builtin_amdgcn_fmed3f(v.x, 0.f, 6.f), __builtin_amdgcn_fmed3f(v.y, 0.f, 6.f), __builtin_amdgcn_fmed3f(v.z, 0.f, 6.f),
+                   __builtin_amdgcn_fmed3f(v.w, 0.f, 6.f)};
+}
+
+template <int S, int TX, int PT>
+struct FusedGeom {
+    static constexpr int RP = 16 / TX;                          // output rows per 16-pixel tile
+    static constexpr int TY = 4 * PT * RP;
+    static constexpr int IH = (TY - 1) * S + 3, IW = (TX - 1) * S + 3;
+    static constexpr int HALF = (IW + 1) / 2;
+    static constexpr int IWP = S == 2 ? 2 * HALF : IW;          // slots per halo row (stride 2: even columns, then odd)
+    static constexpr int NSLOT = IH * IWP, NRT = (NSLOT + 15) / 16;
+};
+
+template <int CIN, int HID, int COUT, int S, bool EXPAND, int HC, int TX, int PT>
+struct FusedCfg : FusedGeom<S, TX, PT> {
+    using G = FusedGeom<S, TX, PT>;
+    static constexpr int HCP = HC + 4;
+    static constexpr int EBUF = G::NRT * 16 * HCP;              // floats per E buffer
+    static constexpr int NCH = HID / HC;
+    static constexpr int NBUF = (EXPAND && NCH > 1 && 2 * EBUF * 4 <= 56 * 1024) ? 2 : 1;
+    static constexpr size_t SMEM = (size_t)NBUF * EBUF * 4;
+};
+
+#ifndef UAVSAL_FUSED_PROBE
+#define UAVSAL_FUSED_PROBE 0      /* timing experiments only (tools/fused_probe.py): 1 no expand MFMA, 2 no depthwise taps,
+                                     4 no projection MFMA, 8 every chunk uses chunk 0's weights, 16 no barriers, 32 no E writes */
+#endif
+
+template <int CIN, int HID, int COUT, int S, bool EXPAND, int HC, int TX, int PT>
+__global__ __launch_bounds__(256, 2) void fused_ir_kernel(const FusedK p) {
+    using Cfg = FusedCfg<CIN, HID, COUT, S, EXPAND, HC, TX, PT>;
+    constexpr int RP = Cfg::RP, TY = Cfg::TY, IH = Cfg::IH, IW = Cfg::IW, HALF = Cfg::HALF, IWP = Cfg::IWP;
+    constexpr int NSLOT = Cfg::NSLOT, NRT = Cfg::NRT, RTW = (NRT + 3) / 4;
+    constexpr int CPL = HC / 4, CQ = CPL / 4, HCP = Cfg::HCP;   // channels per lane in the depthwise phase (= k steps)
+    constexpr int NCH = Cfg::NCH, NCTE = HC / 16, NCT = (COUT + 15) / 16, KE = CIN / 4;
+    constexpr int EBUF = Cfg::EBUF, NBUF = Cfg::NBUF;
+    static_assert(HID % HC == 0 && HC % 16 == 0 && CIN % 8 == 0 && COUT % 4 == 0, "channel blocking");
     static_assert(EXPAND || (HID == CIN && NCH == 1), "without an expand conv the hidden tensor is the input");
+    static_assert(KE % 2 == 0, "x fragments are loaded 8 bytes at a time");
 
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* xs = lds;                                            // [KE][NINP][4]   (EXPAND only)
-    float* es = lds + (EXPAND ? CIN * NINP : 0);                // [HC][ESTR]
-    float* ds = es + HC * ESTR;                                 // [HC][DSTR]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -63,128 +95,186 @@ __global__ __launch_bounds__(256) void fused_ir_kernel(const FusedK p) {
     const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
     const float* inb = p.in + (size_t)n * p.H * p.W * p.ldi;
 
-    // ---- stage the input patch (zero outside the image and in the pad rows) -------------------------
-    for (int idx = tid; idx < NINP * KE; idx += 256) {
-        const int pix = idx / KE, k4 = idx - pix * KE;
-        const int iy = iy0 + pix / IW, ix = ix0 + pix % IW;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (pix < NIN && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
-            v = *reinterpret_cast<const f32x4*>(inb + ((size_t)iy * p.W + ix) * p.ldi + k4 * 4);
-        if (EXPAND) {
-            *reinterpret_cast<f32x4*>(xs + ((size_t)k4 * NINP + pix) * 4) = v;
-        } else {                                   // the input IS the hidden tensor: channel-major scalars
-            es[(k4 * 4 + 0) * ESTR + pix] = v.x; es[(k4 * 4 + 1) * ESTR + pix] = v.y;
-            es[(k4 * 4 + 2) * ESTR + pix] = v.z; es[(k4 * 4 + 3) * ESTR + pix] = v.w;
+    // halo slot -> input pixel; false for the pad slots
+    auto slot_pixel = [&](int slot, int& gy, int& gx) -> bool {
+        const int iy = slot / IWP, rem = slot - iy * IWP;
+        int ix = rem;
+        if (S == 2) { const int par = rem >= HALF ? 1 : 0; ix = 2 * (rem - par * HALF) + par; }
+        gy = iy0 + iy; gx = ix0 + ix;
+        return slot < NSLOT && ix < IW && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+    };
+
+    auto slot_read = [&](int slot) -> bool {          // does the depthwise phase ever read this slot
+        const int iy = slot / IWP, rem = slot - iy * IWP;
+        return slot < NSLOT && (S == 2 ? rem != IWP - 1 || (IW & 1) == 0 : true);
+    };
+
+    // ---- the x fragments of this wave's halo row tiles (round-robin over the 4 waves), kept for every chunk ----
+    float xv[EXPAND ? RTW : 1][EXPAND ? KE : 1];
+    unsigned outside = 0;                      // bit j: this lane's pixel of row tile j lies outside the image (E must be 0 there)
+    unsigned any_outside = 0;                  // bit j, wave-uniform: some lane of row tile j does (interior patches: none)
+    if (EXPAND) {
+#pragma unroll
+        for (int j = 0; j < RTW; ++j) {
+            const int rt = wave + 4 * j;
+            int gy, gx;
+            const bool in = rt < NRT && slot_pixel(rt * 16 + l15, gy, gx);
+            const bool zero = !in && rt < NRT && slot_read(rt * 16 + l15);   // the pad slots are never read: no zero needed
+            outside |= (zero ? 1u : 0u) << j;
+            any_outside |= (__builtin_amdgcn_ballot_w64(zero) != 0ull ? 1u : 0u) << j;
+            const float* src = inb + ((size_t)(in ? gy : 0) * p.W + (in ? gx : 0)) * p.ldi + lq * KE;
+            if (KE % 4 == 0) {
+#pragma unroll
+                for (int s = 0; s < KE; s += 4) {
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (in) v = *reinterpret_cast<const f32x4*>(src + s);
+                    xv[j][s] = v.x; xv[j][s + 1] = v.y; xv[j][s + 2] = v.z; xv[j][s + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < KE; s += 2) {
+                    f32x2 v = {0.f, 0.f};
+                    if (in) v = *reinterpret_cast<const f32x2*>(src + s);
+                    xv[j][s] = v.x; xv[j][s + 1] = v.y;
+                }
+            }
+        }
+    } else {
+        // the input IS the hidden tensor: stage the halo patch pixel-major (zero outside the image and in the pad slots);
+        // all the loads of a thread first, then its LDS writes
+        constexpr int NQ = CIN / 4, NST = (NRT * 16 * NQ + 255) / 256;
+        f32x4 st[NST];
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            const int idx = tid + 256 * i;
+            const int slot = idx / NQ, q = idx - slot * NQ;
+            int gy, gx;
+            st[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (idx < NRT * 16 * NQ && slot_pixel(slot, gy, gx)) st[i] = *reinterpret_cast<const f32x4*>(inb + ((size_t)gy * p.W + gx) * p.ldi + q * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            const int idx = tid + 256 * i;
+            const int slot = idx / NQ, q = idx - slot * NQ;
+            if (idx < NRT * 16 * NQ) *reinterpret_cast<f32x4*>(lds + (size_t)slot * HCP + q * 4) = st[i];
         }
     }
 
-    f32x4 acc_o[NCT];
+    f32x4 acc_o[PT][NCT];
 #pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) acc_o[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) acc_o[pt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     for (int ch = 0; ch < NCH; ++ch) {
-        const int c0 = ch * HC;
-        // ---- this chunk's weights, as MFMA B fragments / per-lane constants (global loads, L2-resident) ----
-        float w1f[EXPAND ? NCTE : 1][EXPAND ? KE : 1], s1f[EXPAND ? NCTE : 1], b1f[EXPAND ? NCTE : 1];
+        const int c0 = (UAVSAL_FUSED_PROBE & 8) ? 0 : ch * HC;
+        // ---- this chunk's weights, as MFMA A fragments / per-lane constants (global loads, cache-resident) ----
+        float w1f[EXPAND ? NCTE : 1][EXPAND ? KE : 1];
+        f32x4 s1q[EXPAND ? NCTE : 1], b1q[EXPAND ? NCTE : 1];
         if (EXPAND) {
 #pragma unroll
             for (int ct = 0; ct < NCTE; ++ct) {
-                const int c = c0 + ct * 16 + l15;
 #pragma unroll
-                for (int s = 0; s < KE; ++s) w1f[ct][s] = p.w1[(size_t)(4 * s + lq) * HID + c];
-                s1f[ct] = p.s1[c]; b1f[ct] = p.b1[c];
+                for (int s = 0; s < KE; ++s) w1f[ct][s] = p.w1[(size_t)(lq * KE + s) * HID + c0 + ct * 16 + l15];
+                s1q[ct] = *reinterpret_cast<const f32x4*>(p.s1 + c0 + ct * 16 + 4 * lq);
+                b1q[ct] = *reinterpret_cast<const f32x4*>(p.b1 + c0 + ct * 16 + 4 * lq);
             }
         }
-        float w2f[NCT][KP];
+        f32x4 wdq[9][CQ], sdq[CQ], bdq[CQ];
+#pragma unroll
+        for (int q = 0; q < CQ; ++q) {
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) wdq[tp][q] = *reinterpret_cast<const f32x4*>(p.wd + (size_t)tp * HID + c0 + lq * CPL + 4 * q);
+            sdq[q] = *reinterpret_cast<const f32x4*>(p.sd + c0 + lq * CPL + 4 * q);
+            bdq[q] = *reinterpret_cast<const f32x4*>(p.bd + c0 + lq * CPL + 4 * q);
+        }
+        float w2f[NCT][CPL];
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) {
             const int co = ct * 16 + l15;
 #pragma unroll
-            for (int s = 0; s < KP; ++s) w2f[ct][s] = co < COUT ? p.w2[(size_t)(c0 + 4 * s + lq) * COUT + co] : 0.f;
+            for (int s = 0; s < CPL; ++s) w2f[ct][s] = co < COUT ? p.w2[(size_t)(c0 + lq * CPL + s) * COUT + co] : 0.f;
         }
-        // depthwise: lane = channel (wave % NJOB) * 16 + l15 of the chunk, pixel part (wave / NJOB, lq)
-        const bool dw_on = wave < NJOB * NPART;
-        const int dj = wave % NJOB, dpart = wave / NJOB;
-        const int dcl = dj * 16 + l15;                          // channel inside the chunk
-        float wdf[9], sdf, bdf;
-#pragma unroll
-        for (int tp = 0; tp < 9; ++tp) wdf[tp] = p.wd[tp * HID + c0 + dcl];
-        sdf = p.sd[c0 + dcl]; bdf = p.bd[c0 + dcl];
 
-        __syncthreads();          // input patch staged (ch == 0) / previous chunk's projection done with D
+        float* eb = lds + (NBUF == 2 ? (ch & 1) * EBUF : 0);
         if (EXPAND) {
-            for (int rt = wave; rt < NRT; rt += 4) {
-                float a[KE];
+            if (NBUF == 1 && ch > 0 && !(UAVSAL_FUSED_PROBE & 16)) __syncthreads();       // the previous chunk's depthwise reads are done
 #pragma unroll
-                for (int s = 0; s < KE; ++s) a[s] = xs[((size_t)s * NINP + rt * 16 + l15) * 4 + lq];
-                float inside[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int pix = rt * 16 + 4 * lq + i;
-                    const int iy = iy0 + pix / IW, ix = ix0 + pix % IW;
-                    inside[i] = (pix < NIN && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? 1.f : 0.f;
-                }
+            for (int j = 0; j < RTW; ++j) {
+                const int rt = wave + 4 * j;
+                if (4 * j + 3 >= NRT && rt >= NRT) continue;   // only the last round can run past the patch (wave-uniform)
+                f32x4 e[NCTE];
 #pragma unroll
                 for (int ct = 0; ct < NCTE; ++ct) {
-                    f32x4 e = {0.f, 0.f, 0.f, 0.f};
+                    e[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int s = 0; s < KE; ++s) e = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], w1f[ct][s], e, 0, 0, 0);
-                    float* dst = es + (size_t)(ct * 16 + l15) * ESTR + rt * 16 + 4 * lq;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)     // zero padding of the depthwise conv: E = 0 outside the image
-                        dst[i] = fminf(fmaxf(fmaf(e[i], s1f[ct], b1f[ct]), 0.f), 6.f) * inside[i];
+                    for (int s = 0; s < KE; ++s) {
+                        if (UAVSAL_FUSED_PROBE & 1) e[ct][s & 3] += w1f[ct][s] * xv[j][s];
+                        else e[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1f[ct][s], xv[j][s], e[ct], 0, 0, 0);
+                    }
+                    e[ct] = relu6_4(e[ct] * s1q[ct] + b1q[ct]);
                 }
-            }
-            __syncthreads();
-        }
-        // ---- depthwise 3x3 (stride S) + BN + ReLU6 -> D ------------------------------------------------
-        if (dw_on) {
-            const float* e = es + (size_t)dcl * ESTR;
-#pragma unroll 2
-            for (int q = 0; q < PXL; ++q) {
-                const int px = (dpart * 4 + lq) * PXL + q;          // output pixel of the 8x8 patch
-                const float* ep = e + ((px >> 3) * S) * IW + (px & 7) * S;
-                float d = 0.f;
+                if ((any_outside >> j) & 1u) {               // zero padding of the depthwise conv: E = 0 outside the image
+                    const bool z = (outside >> j) & 1u;
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
+                    for (int ct = 0; ct < NCTE; ++ct) if (z) e[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
 #pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) d = fmaf(ep[ky * IW + kx], wdf[ky * 3 + kx], d);
-                ds[dcl * DSTR + px] = fminf(fmaxf(fmaf(d, sdf, bdf), 0.f), 6.f);
+                for (int ct = 0; ct < NCTE; ++ct)
+                    if (!(UAVSAL_FUSED_PROBE & 32) || e[ct].x == 123.f) *reinterpret_cast<f32x4*>(eb + (size_t)(rt * 16 + l15) * HCP + ct * 16 + 4 * lq) = e[ct];
             }
         }
-        __syncthreads();          // D visible; es free for the next chunk's expand
-        // ---- projection: output pixels 16*wave .. +15, all output channels, K = this chunk's HC channels ----
+        if (!(UAVSAL_FUSED_PROBE & 16)) __syncthreads();          // E (or the staged input) visible
+        // ---- depthwise 3x3 (stride S) + BN + ReLU6, then the projection with the lane's values as B fragment ----
 #pragma unroll
-        for (int s = 0; s < KP; ++s) {
-            const float a = ds[(4 * s + lq) * DSTR + wave * 16 + l15];
+        for (int pt = 0; pt < PT; ++pt) {
+            const int g = wave * PT + pt;
+            const int orow = g * RP + l15 / TX, ocol = l15 % TX;
+            f32x4 dq[CQ];
 #pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) acc_o[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, w2f[ct][s], acc_o[ct], 0, 0, 0);
+            for (int q = 0; q < CQ; ++q) dq[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ky = 0; ky < ((UAVSAL_FUSED_PROBE & 2) ? 1 : 3); ++ky)
+#pragma unroll
+                for (int kx = 0; kx < ((UAVSAL_FUSED_PROBE & 2) ? 1 : 3); ++kx) {
+                    const int slot = (orow * S + ky) * IWP + (S == 2 ? (kx & 1) * HALF + ocol + (kx >> 1) : ocol + kx);
+                    const f32x4* e = reinterpret_cast<const f32x4*>(eb + (size_t)slot * HCP + lq * CPL);
+#pragma unroll
+                    for (int q = 0; q < CQ; ++q) dq[q] = e[q] * wdq[ky * 3 + kx][q] + dq[q];
+                }
+#pragma unroll
+            for (int q = 0; q < CQ; ++q) dq[q] = relu6_4(dq[q] * sdq[q] + bdq[q]);
+#pragma unroll
+            for (int s = 0; s < CPL; ++s)
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct)
+                    if (UAVSAL_FUSED_PROBE & 4) acc_o[pt][ct][s & 3] += w2f[ct][s] * dq[s >> 2][s & 3];
+                    else acc_o[pt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2f[ct][s], dq[s >> 2][s & 3], acc_o[pt][ct], 0, 0, 0);
         }
     }
 
-    // ---- epilogue: BN (linear), residual, store: lane holds pixels 16*wave + 4*lq + i, channel ct*16 + l15 ----
+    // ---- epilogue: BN (linear), residual, store: lane holds output channels ct*16 + 4*lq .. +3 of pixel l15 of its tiles ----
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
-        const int co = ct * 16 + l15;
+        const int co = ct * 16 + 4 * lq;
         if (co >= COUT) continue;
-        const float sc = p.s2[co], bi = p.b2[co];
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(p.s2 + co), bi = *reinterpret_cast<const f32x4*>(p.b2 + co);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int px = wave * 16 + 4 * lq + i;
-            const int gy = oy0 + (px >> 3), gx = ox0 + (px & 7);
+        for (int pt = 0; pt < PT; ++pt) {
+            const int g = wave * PT + pt;
+            const int gy = oy0 + g * RP + l15 / TX, gx = ox0 + l15 % TX;
             if (gy >= p.Ho || gx >= p.Wo) continue;
             const size_t opix = ((size_t)n * p.Ho + gy) * p.Wo + gx;
-            float v = fmaf(acc_o[ct][i], sc, bi);
-            if (p.res) v += p.res[opix * p.ldr + co];
-            p.out[opix * p.ldo + co] = v;
+            f32x4 v = acc_o[pt][ct] * sc + bi;
+            if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + opix * p.ldr + co);
+            *reinterpret_cast<f32x4*>(p.out + opix * p.ldo + co) = v;
         }
     }
 }
 
-template <int CIN, int HID, int COUT, int S, bool EXPAND, int HC>
+template <int CIN, int HID, int COUT, int S, bool EXPAND, int HC, int TX, int PT>
 int launch_fused(const uavsal_fused_ir_desc* d, hipStream_t s) {
-    constexpr int IH = 7 * S + 3, NIN = IH * IH, NINP = (NIN + 15) / 16 * 16;
-    constexpr size_t SMEM = 4 * ((EXPAND ? CIN * NINP : 0) + (size_t)HC * (NINP + 1) + (size_t)HC * 81);
+    using Cfg = FusedCfg<CIN, HID, COUT, S, EXPAND, HC, TX, PT>;
     FusedK k;
     k.in = d->in; k.w1 = d->w1; k.s1 = d->scale1; k.b1 = d->bias1;
     k.wd = d->wd; k.sd = d->scale_d; k.bd = d->bias_d;
@@ -192,33 +282,59 @@ int launch_fused(const uavsal_fused_ir_desc* d, hipStream_t s) {
     k.res = d->res; k.out = d->out;
     k.ldi = d->ldi; k.ldr = d->ldr; k.ldo = d->ldo; k.H = d->H; k.W = d->W;
     k.Ho = (d->H - 1) / S + 1; k.Wo = (d->W - 1) / S + 1;
-    k.tiles_x = (k.Wo + 7) / 8; k.tiles_y = (k.Ho + 7) / 8;
+    k.tiles_x = (k.Wo + TX - 1) / TX; k.tiles_y = (k.Ho + Cfg::TY - 1) / Cfg::TY;
     const long long nblk = (long long)d->n_img * k.tiles_y * k.tiles_x;
     if (nblk > 0x7fffffffLL) return UAVSAL_ESHAPE;
-    hipLaunchKernelGGL((fused_ir_kernel<CIN, HID, COUT, S, EXPAND, HC>), dim3((unsigned)nblk), dim3(256), SMEM, s, k);
+    static const int once = [] {
+        return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_ir_kernel<CIN, HID, COUT, S, EXPAND, HC, TX, PT>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::SMEM);
+    }();
+    (void)once;
+    hipLaunchKernelGGL((fused_ir_kernel<CIN, HID, COUT, S, EXPAND, HC, TX, PT>), dim3((unsigned)nblk), dim3(256), Cfg::SMEM, s, k);
     return uavsal_launch_status();
+}
+
+// Patch shape: the big one (16x16 outputs at stride 1, 8x16 at stride 2: fewer halo pixels, every weight fragment used
+// 4 / 2 times) when it still gives UAVSAL_FUSED_BIG_MIN workgroups, else 8x8.  A function of the shape only.
+#ifndef UAVSAL_FUSED_BIG_MIN
+#define UAVSAL_FUSED_BIG_MIN 400
+#endif
+template <int CIN, int HID, int COUT, int S, bool EXPAND, int HCS, int HCB>
+int launch_fused_shape(const uavsal_fused_ir_desc* d, hipStream_t s) {
+    constexpr bool BIG_AUTO = !(CIN == 32 && COUT == 64);     // features.7 (80 x-fragment registers per wave in the big patch): 8x8 measured faster at every size
+    constexpr int BPT = S == 1 ? 4 : 2;                       // 16 x 16 or 8 x 16 outputs
+    constexpr int BTY = 4 * BPT;
+    const int Ho = (d->H - 1) / S + 1, Wo = (d->W - 1) / S + 1;
+    const long long big = (long long)d->n_img * ((Ho + BTY - 1) / BTY) * ((Wo + 15) / 16);
+    static const long long big_min = [] { const char* e = getenv("UAVSAL_FUSED_BIG_MIN"); return e ? atoll(e) : (long long)UAVSAL_FUSED_BIG_MIN; }();
+    const bool use_big = d->tile == 2 || (d->tile == 0 && BIG_AUTO && big >= big_min);
+    return use_big ? launch_fused<CIN, HID, COUT, S, EXPAND, HCB, 16, BPT>(d, s) : launch_fused<CIN, HID, COUT, S, EXPAND, HCS, 8, 1>(d, s);
 }
 
 // the channel / stride combinations that exist as instances: MobileNetV2 features[1..7] (model_feature.py:62-66)
 int dispatch(const uavsal_fused_ir_desc* d, hipStream_t s, bool launch) {
+#define UAVSAL_FUSED_UNPAREN(...) __VA_ARGS__
 #define UAVSAL_FUSED_CASE(CIN, HID, COUT, S, EXP, HCC)                                                   \
     if (d->Cin == CIN && d->hidden == HID && d->Cout == COUT && d->stride == S && (d->w1 != nullptr) == EXP) \
-        return launch ? launch_fused<CIN, HID, COUT, S, EXP, HCC>(d, s) : 1;
-#ifndef UAVSAL_FUSED_HC_A
-#define UAVSAL_FUSED_HC_A 48      /* hidden chunk of the stride-1 blocks */
+        return launch ? launch_fused_shape<CIN, HID, COUT, S, EXP, UAVSAL_FUSED_UNPAREN HCC>(d, s) : 1;
+#ifndef UAVSAL_FUSED_HCS
+#define UAVSAL_FUSED_HCS 16       /* hidden chunk of the blocks with an expand conv, 8x8 patches */
 #endif
-#ifndef UAVSAL_FUSED_HC_B
-#define UAVSAL_FUSED_HC_B 32      /* ... of the stride-2 blocks with hidden % 32 == 0 */
+#ifndef UAVSAL_FUSED_HCS144
+#define UAVSAL_FUSED_HCS144 16    /* ... hidden = 144 (16 or 48) */
 #endif
-#ifndef UAVSAL_FUSED_HC_C
-#define UAVSAL_FUSED_HC_C 16      /* ... of features.4 (hidden 144: 16 or 48) */
+#ifndef UAVSAL_FUSED_HCB
+#define UAVSAL_FUSED_HCB 16       /* ... big patches */
 #endif
-    UAVSAL_FUSED_CASE(32, 32, 16, 1, false, 32)     // features.1  (t = 1: no expand conv)
-    UAVSAL_FUSED_CASE(16, 96, 24, 2, true, UAVSAL_FUSED_HC_B)      // features.2
-    UAVSAL_FUSED_CASE(24, 144, 24, 1, true, UAVSAL_FUSED_HC_A)     // features.3
-    UAVSAL_FUSED_CASE(24, 144, 32, 2, true, UAVSAL_FUSED_HC_C)     // features.4
-    UAVSAL_FUSED_CASE(32, 192, 32, 1, true, UAVSAL_FUSED_HC_A)     // features.5, features.6
-    UAVSAL_FUSED_CASE(32, 192, 64, 2, true, UAVSAL_FUSED_HC_B)     // features.7
+#ifndef UAVSAL_FUSED_HCB144
+#define UAVSAL_FUSED_HCB144 16
+#endif
+    UAVSAL_FUSED_CASE(32, 32, 16, 1, false, (32, 32))     // features.1  (t = 1: no expand conv)
+    UAVSAL_FUSED_CASE(16, 96, 24, 2, true, (UAVSAL_FUSED_HCS, UAVSAL_FUSED_HCB))      // features.2
+    UAVSAL_FUSED_CASE(24, 144, 24, 1, true, (UAVSAL_FUSED_HCS144, UAVSAL_FUSED_HCB144))     // features.3
+    UAVSAL_FUSED_CASE(24, 144, 32, 2, true, (UAVSAL_FUSED_HCS144, UAVSAL_FUSED_HCB144))     // features.4
+    UAVSAL_FUSED_CASE(32, 192, 32, 1, true, (UAVSAL_FUSED_HCS, UAVSAL_FUSED_HCB))     // features.5, features.6
+    UAVSAL_FUSED_CASE(32, 192, 64, 2, true, (UAVSAL_FUSED_HCS, UAVSAL_FUSED_HCB))     // features.7
 #undef UAVSAL_FUSED_CASE
     return launch ? UAVSAL_ESHAPE : 0;
 }
@@ -234,7 +350,12 @@ extern "C" int uavsal_fused_ir(const uavsal_fused_ir_desc* d, uavsal_stream_t st
     if (!d || !d->in || !d->wd || !d->scale_d || !d->bias_d || !d->w2 || !d->scale2 || !d->bias2 || !d->out) return UAVSAL_EINVAL;
     if (d->w1 && (!d->scale1 || !d->bias1)) return UAVSAL_EINVAL;
     if (d->n_img <= 0 || d->H <= 0 || d->W <= 0) return UAVSAL_EINVAL;
-    if ((d->ldi & 3) || d->ldi < d->Cin || d->ldo < d->Cout || !uavsal_aligned16(d->in)) return UAVSAL_EALIGN;
+    if ((d->ldi & 3) || d->ldi < d->Cin || (d->ldo & 3) || d->ldo < d->Cout || !uavsal_aligned16(d->in) || !uavsal_aligned16(d->out) ||
+        !uavsal_aligned16(d->wd) || !uavsal_aligned16(d->scale_d) || !uavsal_aligned16(d->bias_d) || !uavsal_aligned16(d->scale2) ||
+        !uavsal_aligned16(d->bias2) || (d->w1 && (!uavsal_aligned16(d->scale1) || !uavsal_aligned16(d->bias1))) ||
+        (d->res && ((d->ldr & 3) || !uavsal_aligned16(d->res))))
+        return UAVSAL_EALIGN;
+    if (d->tile < 0 || d->tile > 2) return UAVSAL_EINVAL;
     if (d->res && (d->ldr < d->Cout || d->stride != 1 || d->Cin != d->Cout)) return UAVSAL_ESHAPE;
     return dispatch(d, (hipStream_t)stream, true);
 }

@@ -239,7 +239,7 @@ def dw3x3(x, weight, scale, bias, stride=1, dilation=1, act=L.ACT_RELU6, out=Non
     return sp if split_out else out
 
 
-def fused_ir(x, w1, bn1, wd, bnd, w2, bn2, stride=1, residual=False):
+def fused_ir(x, w1, bn1, wd, bnd, w2, bn2, stride=1, residual=False, tile=0):
     """One inverted-residual block as a single launch (uavsal_fused_ir).  `x` NHWC; `w1` [hid,Cin,1,1] or None
     (no expand conv); `wd` [hid,1,3,3]; `w2` [Cout,hid,1,1]; bn* = (scale, bias) folded BatchNorms."""
     lib = L.load()
@@ -264,7 +264,7 @@ def fused_ir(x, w1, bn1, wd, bnd, w2, bn2, stride=1, residual=False):
     if residual:
         d.res, d.ldr = ip, ldi
     d.out, d.ldo = out.data_ptr(), cout
-    d.n_img, d.H, d.W, d.Cin, d.hidden, d.Cout, d.stride = n, h, w, cin, hid, cout, stride
+    d.n_img, d.H, d.W, d.Cin, d.hidden, d.Cout, d.stride, d.tile = n, h, w, cin, hid, cout, stride, tile
     if not int(lib.uavsal_fused_ir_supported(C.byref(d))):
         raise RuntimeError("no fused inverted-residual instance for (Cin, hidden, Cout, stride) = %s" % ((cin, hid, cout, stride),))
     L.check(lib.uavsal_fused_ir(C.byref(d), _stream(x)), "uavsal_fused_ir")

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define UAVSAL_ABI_VERSION 13
+#define UAVSAL_ABI_VERSION 14
 
 /* argument errors */
 #define UAVSAL_EINVAL   (-1)  /* null pointer / non-positive size */
@@ -228,7 +228,8 @@ int uavsal_dw_variant(const uavsal_dw_desc* d);
  * uavsal_fused_ir_supported tells.  Exact fp32 FMA arithmetic whatever the GEMM precision of the plan.
  * Weights (host-packed, fp32): w1 [Cin][hidden] (= conv weight transposed), wd [9][hidden] tap-major as in
  * uavsal_dw_desc, w2 [hidden][Cout]; scale* / bias* are the folded BatchNorms.  res (or NULL) is the block
- * input for the residual connection (stride 1, Cin == Cout): out = bn3(...) + res.
+ * input for the residual connection (stride 1, Cin == Cout): out = bn3(...) + res.  in / out / res rows and every
+ * per-channel vector are read and written 16 bytes at a time: 16-byte aligned bases, ld* multiples of 4.
  */
 typedef struct uavsal_fused_ir_desc {
     const float* in;   int32_t ldi;
@@ -238,6 +239,7 @@ typedef struct uavsal_fused_ir_desc {
     const float* res;  int32_t ldr;
     float*       out;  int32_t ldo;
     int32_t n_img, H, W, Cin, hidden, Cout, stride;
+    int32_t tile;                /* output patch per workgroup: 0 = by the launch size, 1 = 8x8, 2 = 16x16 (stride 1) / 8x16 (stride 2) */
 } uavsal_fused_ir_desc;
 
 int uavsal_fused_ir(const uavsal_fused_ir_desc* d, uavsal_stream_t stream);

@@ -733,8 +733,9 @@ FUSED_CASES = [
 ]
 
 
+@pytest.mark.parametrize("tile", [1, 2])          # 8x8 patches / 16x16 (stride 1), 8x16 (stride 2)
 @pytest.mark.parametrize("case", FUSED_CASES)
-def test_fused_inverted_residual(ops, case):
+def test_fused_inverted_residual(ops, case, tile):
     n, h, w, cin, hid, cout, stride, res = case
     x = rnd((n, cin, h, w), 101, 2.0)
     bn = lambda c, s: (rnd((c,), s) * 0.5 + 1.0, rnd((c,), s + 1))
@@ -748,7 +749,7 @@ def test_fused_inverted_residual(ops, case):
     ref = aff(F.conv2d(dd, w2), b2)
     if res:
         ref = ref + x
-    got = ops.fused_ir(nhwc(x), w1, b1, wd, bd, w2, b2, stride=stride, residual=res)
+    got = ops.fused_ir(nhwc(x), w1, b1, wd, bd, w2, b2, stride=stride, residual=res, tile=tile)
     assert tuple(got.shape) == (n, ref.shape[2], ref.shape[3], cout)
     err = (nchw(got) - ref).abs().max().item()
     assert err <= 2e-5 * max(1.0, ref.abs().max().item()), (case, err)
