@@ -118,10 +118,10 @@ class Engine:
         # (model.winograd, default on; UAVSAL_WINOGRAD=0 switches it off, UAVSAL_WINOGRAD_STEPS = 0 / 8 / 11: the per-step
         # convolutions of the recurrence too, with that GEMM tile)
         self.winograd = precision == "f32" and bool(getattr(model, "winograd", True)) and os.environ.get("UAVSAL_WINOGRAD", "1") != "0"
-        self.winograd_steps = int(os.environ.get("UAVSAL_WINOGRAD_STEPS", "8"))
+        self.winograd_steps = int(os.environ.get("UAVSAL_WINOGRAD_STEPS", "-1"))     # -1: by the number of clips (below)
         # output tile of the transforms: 2 = F(2x2, 3x3), 4 = F(4x4, 3x3); for the all-frames convs / for the recurrence steps
         self.winograd_r = int(os.environ.get("UAVSAL_WINOGRAD_R", "4"))
-        self.winograd_step_r = int(os.environ.get("UAVSAL_WINOGRAD_STEP_R", "2"))
+        self.winograd_step_r = int(os.environ.get("UAVSAL_WINOGRAD_STEP_R", "0"))   # 0: by the number of clips
         self.fuse_blocks = bool(getattr(model, "fuse_blocks", True))
         self._split_want = set()
         self._no_shadow = set()
@@ -849,9 +849,13 @@ class Engine:
             a = V(a.t, self.n_seq, h, w, 256, 256, a.coff)
             strides = {"a": hw if t == 0 else Lq * hw, "o": Lq * hw, "r": Lq * hw, "x": Lq * hw}
             if self.winograd and self.winograd_steps:
+                # one clip: 920 tiles of 2x2 fill the chip with 128x128 GEMM tiles; four clips and more: F(4x4) (1.78x
+                # fewer FLOPs, smaller transforms) on 64x64 tiles (measured: 4.54 vs 4.61 ms at one clip, 29.47 vs 28.80 at eight)
+                many = self.n_seq >= 4
                 self.conv3_wino("twa.step%d" % t, a, rc, None, ro.frames(t, self.n_seq), NONE, wslice=(256, 512),
                                 n_img=self.n_seq, strides=strides, twa=(xf.frames(t, self.n_seq), pre.frames(t, self.n_seq)),
-                                gemm_tile=self.winograd_steps, r=self.winograd_step_r)
+                                gemm_tile=self.winograd_steps if self.winograd_steps > 0 else (11 if many else 8),
+                                r=self.winograd_step_r or (4 if many else 2))
                 continue
             self.conv("twa.step%d" % t, a, rc, None, ro.frames(t, self.n_seq), NONE, taps=9, wslice=(256, 512),
                       epi=L.EPI_TWA, res=xf.frames(t, self.n_seq), aux=pre.frames(t, self.n_seq),
