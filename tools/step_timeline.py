@@ -1,8 +1,12 @@
 """One timed step out of a `rocprofv3 --kernel-trace` of bench.py: per stream (queue) the busy time and the gaps between
 consecutive kernels, the longest gaps, and the union of all kernels' busy intervals (device not idle).
-  python tools/step_timeline.py <kernel_trace.csv> [step_index_from_the_end]"""
+  python tools/step_timeline.py <kernel_trace.csv> [step_index_from_the_end] [--list]      (--list: every launch of the step,
+  start offset, duration and queue, in start order)"""
 import csv, sys, collections, re
 
+LIST = "--list" in sys.argv
+if LIST:
+    sys.argv.remove("--list")
 rows = []
 for r in csv.DictReader(open(sys.argv[1])):
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "0")))
@@ -20,6 +24,10 @@ def short(n):
 byq = collections.defaultdict(list)
 for s, e, n, q in step:
     byq[q].append((s, e, n))
+if LIST:
+    qid = {q: i for i, q in enumerate(sorted(byq, key=lambda q: -len(byq[q])))}
+    for s, e, n, q in step:
+        print("%8.1f us  +%7.1f us  lane %d %s%s" % ((s - t0) / 1e3, (e - s) / 1e3, qid[q], "        " * qid[q], short(n)))
 for q, ks in sorted(byq.items(), key=lambda kv: -len(kv[1])):
     busy = sum(e - s for s, e, _ in ks)
     gaps = [(ks[i + 1][0] - ks[i][1], ks[i][2], ks[i + 1][2]) for i in range(len(ks) - 1)]
