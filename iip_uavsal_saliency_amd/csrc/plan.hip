@@ -223,6 +223,7 @@ extern "C" int uavsal_plan_run(uavsal_plan* p, int first, int last, uavsal_strea
         const Op& op = p->ops[i];
         if (op.kind == OP_FORK || op.kind == OP_JOIN) {
             if (!lanes) continue;
+            // (side lanes on high-priority queues, hipStreamCreateWithPriority: the whole step takes 8.8 ms instead of 4.5)
             if (!p->side[op.lane] &&
                 hipStreamCreateWithFlags(&p->side[op.lane], hipStreamNonBlocking) != hipSuccess) return (int)hipGetLastError();
             if (!p->events[i] &&

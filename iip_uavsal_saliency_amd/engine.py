@@ -715,6 +715,9 @@ class Engine:
         x4 = self._buf("x4", N, c4.h, c4.w, 128)
         cat = self._buf("srf_cat", N, h, w, 448)
         branches = (sf.lv5_aspp2, sf.lv5_aspp3, sf.lv5_aspp4)
+        aspp_lanes = int(os.environ.get("UAVSAL_ASPP_LANES", "1"))
+        fork = self.fork if aspp_lanes else (lambda lane: None)
+        join = self.join if aspp_lanes else (lambda lane: None)
         if int(os.environ.get("UAVSAL_ASPP_MERGE", "1")) and all(b.expand_ratio != 1 for b in branches):
             # the three dilated branches expand the SAME map with the same shape: one GEMM with their output channels
             # side by side (320 -> 3 x 1920: 675 tiles instead of three launches of 225 fighting for the chip on three
@@ -723,26 +726,26 @@ class Engine:
             e3 = self._scr("E3", N, c5.h, c5.w, 3 * hid)
             self.conv("aspp.pw", c5, [b.conv[0][0] for b in branches], [b.conv[0][1] for b in branches], e3, R6)
             for bi, b in enumerate(branches):
-                self.fork(3 + bi)
+                fork(3 + bi)
                 self.ir_block("aspp%d" % (bi + 2), c5, b, aspp.slice(256 * (bi + 1), 256), expanded=e3.slice(bi * hid, hid))
                 self.main()
         else:
             for bi, b in enumerate(branches):
-                self.fork(3 + bi)
+                fork(3 + bi)
                 self.ir_block("aspp%d" % (bi + 2), c5, b, aspp.slice(256 * (bi + 1), 256))
                 self.main()
-        self.fork(6)
+        fork(6)
         self.conv("conv_lv4", c4, sf.conv_lv4[0], sf.conv_lv4[1], x4, R6)
         self.bilinear("up_c4", x4, cat.slice(256, 128))
         self.conv("conv_lv3", c3, sf.conv_lv3[0], sf.conv_lv3[1], cat.slice(384, 64), R6)
         self.main()
         self.conv("aspp1", c5, sf.lv5_aspp1[0], sf.lv5_aspp1[1], aspp.slice(0, 256), R6)
-        self.join(3)
-        self.join(4)
-        self.join(5)
+        join(3)
+        join(4)
+        join(5)
         self.conv("conv_lv5", aspp, sf.conv_lv5[0], sf.conv_lv5[1], x5, R6)
         self.bilinear("up_c5", x5, cat.slice(0, 256))
-        self.join(6)
+        join(6)
         x = self._buf("sfnet", N, h, w, 256)
         if self.winograd:
             self.conv3_wino("conv_last", cat, sf.conv_last[0], sf.conv_last[1], x, R6, r=self.winograd_r)
