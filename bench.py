@@ -302,7 +302,7 @@ def main():
     ap.add_argument("--lanes", type=int, default=1, help="run independent branches on parallel streams / graph branches")
     ap.add_argument("--fuse-dw", type=int, default=-1, help="-1 engine default, 0/1 force the fused depthwise->projection GEMM")
     ap.add_argument("--stream-k", type=int, default=1, help="fp32 GEMMs: stream-K when whole tiles would idle CUs")
-    ap.add_argument("--presplit", type=int, default=1, help="f16x3: producers also write split shadows and the eligible GEMMs "
+    ap.add_argument("--presplit", type=int, default=-1, help="f16x3: producers also write split shadows and the eligible GEMMs "
                     "stage both operands by LDS-DMA (0: every GEMM re-splits its fp32 input while staging)")
     ap.add_argument("--fuse-blocks", type=int, default=1, help="features[1..7] as one fused launch per block (0: three launches)")
     ap.add_argument("--sync-errors", type=int, default=-1, help="-1: model default (forward_clips is asynchronous: device errors "
@@ -341,7 +341,7 @@ def main():
     model.fuse_dw = None if args.fuse_dw < 0 else bool(args.fuse_dw)
     model.use_lanes = bool(args.lanes)
     model.stream_k = bool(args.stream_k)
-    model.presplit = bool(args.presplit)
+    model.presplit = None if args.presplit < 0 else bool(args.presplit)
     model.fuse_blocks = bool(args.fuse_blocks)
     model.sync_errors = None if args.sync_errors < 0 else bool(args.sync_errors)
 

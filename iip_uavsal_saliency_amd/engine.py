@@ -113,7 +113,8 @@ class Engine:
         # by their producers, so that GEMM stages both operands by LDS-DMA with no conversion work.  The sizing
         # pass finds out which buffers are wanted (`_split_want`) and which cannot have one because a producer
         # does not write shadows (`_no_shadow`).
-        self.split_mode = precision == "f16x3" and bool(getattr(model, "presplit", True))
+        presplit = getattr(model, "presplit", None)
+        self.split_mode = precision == "f16x3" and (bool(presplit) if presplit is not None else n_seq >= 4)
         # exact-fp32 mode: the dense 3x3 convs (conv_last, the ConvTWA gate conv) as Winograd F(2x2, 3x3)
         # (model.winograd, default on; UAVSAL_WINOGRAD=0 switches it off, UAVSAL_WINOGRAD_STEPS = 0 / 8 / 11: the per-step
         # convolutions of the recurrence too, with that GEMM tile)

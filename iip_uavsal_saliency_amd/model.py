@@ -166,7 +166,8 @@ class UAVSal(nn.Module):
         self.fuse_dw = None             # None: engine default (fp32: LDS-halo fused dw->projection on the big blocks; engine.py)
         self.use_lanes = True           # independent branches on parallel streams / graph branches
         self.stream_k = True            # fp32 GEMMs: split K across workgroups when whole tiles leave CUs idle
-        self.presplit = True            # f16x3: producers also write hi/lo fp16 shadows, GEMMs stage them by LDS-DMA
+        self.presplit = None            # f16x3: producers also write hi/lo fp16 shadows, GEMMs stage them by LDS-DMA;
+                                        # None = from four clips up (measured: 17.71 vs 18.00 ms at eight clips, 3.240 vs 3.217 at one)
         self.fuse_blocks = True         # features[1..7]: whole inverted-residual block in one launch (uavsal_fused_ir)
         self.winograd = True            # exact-fp32 mode: dense 3x3 convs as Winograd F(4x4 / 2x2, 3x3) (csrc/winograd.hip)
         # A device-side error (a stream-K hand-off that timed out) always NaN-fills the returned map and state.
@@ -272,7 +273,7 @@ class UAVSal(nn.Module):
         key = (str(device), n_seq, seq_len, H, W, self.time_dims if ctx_mode == "tile" else seq_len,
                ctx_mode, self.precision, bool(taps), in_dtype, bool(self.use_graph), self.rnn_type, self.fuse_dw, bool(self.use_lanes),
                bool(self.stream_k), bool(self.persistent_state), tuple(getattr(self, "_sk_debug", (0, 0))),
-               bool(self.presplit), bool(self.fuse_blocks), bool(getattr(self, "winograd", True)))
+               self.presplit, bool(self.fuse_blocks), bool(getattr(self, "winograd", True)))
         eng = self._engines.get(key)
         if eng is None:
             while len(self._engines) >= max(1, int(self.max_engines)):
