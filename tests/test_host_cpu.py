@@ -115,6 +115,35 @@ def test_pack_dw_and_stem():
     assert s.shape == (27, 32) and s[1 * 9 + 2 * 3 + 1, 7] == ws[7, 1, 2, 1]
 
 
+@pytest.mark.parametrize("r", [2, 4])
+def test_pack_wino_weight_is_the_winograd_filter_transform(r):
+    """packing.pack_wino_weight: the (r + 2)^2 filter matrices (G g G^T)_k in the layout of the grouped GEMM
+    (uavsal_conv_desc.w_group_stride).  Checked through the Winograd identity on the CPU in fp64:
+    A^T [ sum_c U_k .* (B^T d B)_k ] A == conv3x3(d, g) for one r x r output tile (csrc/winograd.hip uses the same
+    B^T / A^T; the tile transforms are restated here from Lavin & Gray, points 0, +-1 (r = 2) and 0, +-1, +-2 (r = 4))."""
+    bt = {2: [[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]],
+          4: [[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0],
+              [0, 4, 0, -5, 0, 1]]}[r]
+    at = {2: [[1, 1, 1, 0], [0, 1, -1, -1]],
+          4: [[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]]}[r]
+    bt, at = torch.tensor(bt, dtype=torch.float64), torch.tensor(at, dtype=torch.float64)
+    pp = r + 2
+    g = torch.Generator().manual_seed(7)
+    cin, cout = 40, 24                                   # not multiples of 32: the packing pads both
+    w = torch.randn((cout, cin, 3, 3), generator=g, dtype=torch.float64)
+    d = torch.randn((cin, pp, pp), generator=g, dtype=torch.float64)
+    packed = P.pack_wino_weight(w.float(), r)
+    kpad, npad = P.roundup(cin, 32), P.roundup(cout, 32)
+    u = packed.view(torch.float32).reshape(pp * pp, npad, kpad).double()
+    assert torch.count_nonzero(u[:, cout:, :]) == 0 and torch.count_nonzero(u[:, :, cin:]) == 0
+    v = torch.einsum("ij,cjk,lk->cil", bt, d, bt).reshape(cin, pp * pp)                  # (B^T d B)_k per channel
+    m = torch.einsum("koc,ck->ok", u[:, :cout, :cin], v).reshape(cout, pp, pp)          # the GEMM, per plane k
+    y = torch.einsum("ij,ojk,lk->oil", at, m, at)                                        # A^T m A
+    ref = F.conv2d(d[None], w)[0]                                                        # valid conv of the patch = r x r outputs
+    assert tuple(y.shape) == tuple(ref.shape) == (cout, r, r)
+    assert (y - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()                 # U was rounded to fp32 once
+
+
 def test_dropin_schema_matches_reference():
     """Same keys/shapes as the oracle tree (itself pinned to the reference's 51.59 MB known
     answer, Tools/Getmodelsize_demo.py:93) and the attribute names that tool touches (:52-82)."""
