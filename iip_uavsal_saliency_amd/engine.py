@@ -63,6 +63,14 @@ class V:
 # expanded values (pixels x hidden channels) from which the fused depthwise -> projection launch beats depthwise +
 # projection launches (tools/dwproj_probe.py: 8 x 45 x 80 x 1152 wins, 2 x 23 x 41 x 96 loses)
 FUSE_DW_MIN_WORK = 8 * 45 * 80 * 512
+# ... and the share of a map's 8 x 16 pixel patches that lies outside the map must be small: the kernel computes whole
+# patches (45x80: 1.07, 23x40: 1.25, 12x20: 2.13).  Eight clips, fp32, features.8-17 on the 23x40 / 12x20 maps: 1259 us fused
+# against 911 us as depthwise + projection launches (features.17 alone 282 vs 128)
+FUSE_DW_MAX_WASTE = float(os.environ.get("UAVSAL_FUSE_DW_MAX_WASTE", "1.15"))
+
+
+def _dwproj_patch_waste(h, w):
+    return ((h + 7) // 8 * 8) * ((w + 15) // 16 * 16) / float(h * w)
 
 
 class Engine:
@@ -589,7 +597,7 @@ class Engine:
         ho, wo = (x.h - 1) // stride + 1, (x.w - 1) // stride + 1
         if dil == 1 and blk.expand_ratio != 1 and (self.fuse_dw or (
                 self.fuse_dw is None and self.prec_name in ("f32", "f16x3") and stride == 1 and blk.hidden % 16 == 0
-                and x.n * x.h * x.w * blk.hidden >= FUSE_DW_MIN_WORK)):
+                and x.n * x.h * x.w * blk.hidden >= FUSE_DW_MIN_WORK and _dwproj_patch_waste(x.h, x.w) <= FUSE_DW_MAX_WASTE)):
             # depthwise computed inside the projection GEMM's loader: D never reaches HBM
             self.conv(name + ".dwpl", e, pl, plbn, out, final_act, res=x if blk.use_res_connect else None,
                       dw=(dwc, dwbn, stride))
