@@ -4,15 +4,17 @@
 // tensors E and D never reach HBM: at 360x640 the unfused features.2 block moves 482 MB (E alone is 177 MB
 // written + 177 MB read) for 40 MB of block input + output.
 //
-// One 256-thread workgroup produces a TY x TX patch of output pixels of one image (8x8 when the launch has few patches,
+// One 256-thread workgroup produces a TY x TX patch of output pixels of one image (4x16 when the launch has few patches,
 // 16x16 / 8x16 otherwise: each wave then owns PT = 4 / 2 tiles of 16 pixels and every weight fragment it loads is used
 // that many times).  The hidden channels are processed in chunks of HC:
 //   expand : E^T[channel][halo pixel] = W1^T . x^T on v_mfma_f32_16x16x4_f32 (exact fp32).  B = x read ONCE from global
 //            memory straight into the fragment registers (lane = (halo pixel, channel group): KE contiguous channels) and
 //            kept for all chunks; A = W1^T in VGPRs.  The accumulator lane holds 4 consecutive hidden channels of one
 //            pixel: relu6(bn1), EXACT ZERO outside the image (the depthwise conv pads E, not x), one ds_write_b128 into
-//            E[pixel][HC + 4] (pixel-major, 16-byte pad: consecutive pixels land on different bank groups; for stride 2
-//            the halo columns are stored even columns first, then odd, so that a tap reads consecutive slots);
+//            E[channel quad][halo slot][4] -- planes of 16 bytes per pixel, plane size a multiple of 16 slots: the 16 lanes
+//            one LDS cycle of a ds_read_b128 serves ({0-3, 12-15, 20-27}, ...: MI355X_MICROARCH.md, LDS) are 8 + 8 pixels of
+//            two neighbouring planes and cover the 64 banks exactly when the pixels are consecutive slots, which they are
+//            (patches are 16 outputs wide; for stride 2 the halo columns are stored even columns first, then odd);
 //   dw     : lane = (output pixel l & 15, channel group l >> 4 of HC/4 channels): nine taps x HC/16 ds_read_b128, tap
 //            weights / BN in VGPRs, relu6(bn2) -- and the lane's values ARE its B fragment of the projection MFMA
 //            (k index (l >> 4, s) <-> channel (l >> 4) * HC/4 + s), so D never goes through LDS;
@@ -58,10 +60,13 @@ struct FusedGeom {
 template <int CIN, int HID, int COUT, int S, bool EXPAND, int HC, int TX, int PT>
 struct FusedCfg : FusedGeom<S, TX, PT> {
     using G = FusedGeom<S, TX, PT>;
-    static constexpr int HCP = HC + 4;
-    static constexpr int EBUF = G::NRT * 16 * HCP;              // floats per E buffer
+    // E in LDS, float offset of (channel quad qp, halo slot): with an expand conv, planes [qp][slot][4]; without one (the
+    // staged input: 8 lanes write the 128 contiguous bytes of a pixel) pixel-major rows of HC + 4 floats
+    static constexpr int PLANE = EXPAND ? G::NRT * 16 * 4 : 4;
+    static constexpr int SLOTF = EXPAND ? 4 : HC + 4;
+    static constexpr int EBUF = EXPAND ? (HC / 4) * PLANE : G::NRT * 16 * SLOTF;   // floats per E buffer
     static constexpr int NCH = HID / HC;
-    static constexpr int NBUF = (EXPAND && NCH > 1 && 2 * EBUF * 4 <= 56 * 1024) ? 2 : 1;
+    static constexpr int NBUF = (EXPAND && NCH > 1 && 2 * EBUF * 4 <= 78 * 1024) ? 2 : 1;   // two workgroups per CU either way
     static constexpr size_t SMEM = (size_t)NBUF * EBUF * 4;
 };
 
@@ -75,7 +80,7 @@ __global__ __launch_bounds__(256, 2) void fused_ir_kernel(const FusedK p) {
     using Cfg = FusedCfg<CIN, HID, COUT, S, EXPAND, HC, TX, PT>;
     constexpr int RP = Cfg::RP, TY = Cfg::TY, IH = Cfg::IH, IW = Cfg::IW, HALF = Cfg::HALF, IWP = Cfg::IWP;
     constexpr int NSLOT = Cfg::NSLOT, NRT = Cfg::NRT, RTW = (NRT + 3) / 4;
-    constexpr int CPL = HC / 4, CQ = CPL / 4, HCP = Cfg::HCP;   // channels per lane in the depthwise phase (= k steps)
+    constexpr int CPL = HC / 4, CQ = CPL / 4, PLANE = Cfg::PLANE, SLOTF = Cfg::SLOTF;   // channels per lane in the depthwise phase (= k steps)
     constexpr int NCH = Cfg::NCH, NCTE = HC / 16, NCT = (COUT + 15) / 16, KE = CIN / 4;
     constexpr int EBUF = Cfg::EBUF, NBUF = Cfg::NBUF;
     static_assert(HID % HC == 0 && HC % 16 == 0 && CIN % 8 == 0 && COUT % 4 == 0, "channel blocking");
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void fused_ir_kernel(const FusedK p) {
         for (int i = 0; i < NST; ++i) {
             const int idx = tid + 256 * i;
             const int slot = idx / NQ, q = idx - slot * NQ;
-            if (idx < NRT * 16 * NQ) *reinterpret_cast<f32x4*>(lds + (size_t)slot * HCP + q * 4) = st[i];
+            if (idx < NRT * 16 * NQ) *reinterpret_cast<f32x4*>(lds + (size_t)q * PLANE + slot * SLOTF) = st[i];
         }
     }
 
@@ -221,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void fused_ir_kernel(const FusedK p) {
                 }
 #pragma unroll
                 for (int ct = 0; ct < NCTE; ++ct)
-                    if (!(UAVSAL_FUSED_PROBE & 32) || e[ct].x == 123.f) *reinterpret_cast<f32x4*>(eb + (size_t)(rt * 16 + l15) * HCP + ct * 16 + 4 * lq) = e[ct];
+                    if (!(UAVSAL_FUSED_PROBE & 32) || e[ct].x == 123.f) *reinterpret_cast<f32x4*>(eb + (size_t)(ct * 4 + lq) * PLANE + (rt * 16 + l15) * SLOTF) = e[ct];
             }
         }
         if (!(UAVSAL_FUSED_PROBE & 16)) __syncthreads();          // E (or the staged input) visible
@@ -238,9 +243,9 @@ __global__ __launch_bounds__(256, 2) void fused_ir_kernel(const FusedK p) {
 #pragma unroll
                 for (int kx = 0; kx < ((UAVSAL_FUSED_PROBE & 2) ? 1 : 3); ++kx) {
                     const int slot = (orow * S + ky) * IWP + (S == 2 ? (kx & 1) * HALF + ocol + (kx >> 1) : ocol + kx);
-                    const f32x4* e = reinterpret_cast<const f32x4*>(eb + (size_t)slot * HCP + lq * CPL);
+                    const float* e = eb + (size_t)(lq * CQ) * PLANE + slot * SLOTF;
 #pragma unroll
-                    for (int q = 0; q < CQ; ++q) dq[q] = e[q] * wdq[ky * 3 + kx][q] + dq[q];
+                    for (int q = 0; q < CQ; ++q) dq[q] = *reinterpret_cast<const f32x4*>(e + (size_t)q * PLANE) * wdq[ky * 3 + kx][q] + dq[q];
                 }
 #pragma unroll
             for (int q = 0; q < CQ; ++q) dq[q] = relu6_4(dq[q] * sdq[q] + bdq[q]);
@@ -295,20 +300,20 @@ int launch_fused(const uavsal_fused_ir_desc* d, hipStream_t s) {
 }
 
 // Patch shape: the big one (16x16 outputs at stride 1, 8x16 at stride 2: fewer halo pixels, every weight fragment used
-// 4 / 2 times) when it still gives UAVSAL_FUSED_BIG_MIN workgroups, else 8x8.  A function of the shape only.
+// 4 / 2 times) when it still gives UAVSAL_FUSED_BIG_MIN workgroups, else 4x16.  A function of the shape only.
 #ifndef UAVSAL_FUSED_BIG_MIN
 #define UAVSAL_FUSED_BIG_MIN 400
 #endif
 template <int CIN, int HID, int COUT, int S, bool EXPAND, int HCS, int HCB>
 int launch_fused_shape(const uavsal_fused_ir_desc* d, hipStream_t s) {
-    constexpr bool BIG_AUTO = !(CIN == 32 && COUT == 64);     // features.7 (80 x-fragment registers per wave in the big patch): 8x8 measured faster at every size
+    constexpr bool BIG_AUTO = !(CIN == 32 && COUT == 64);     // features.7 (80 x-fragment registers per wave in the big patch): the small patch measured faster at every size
     constexpr int BPT = S == 1 ? 4 : 2;                       // 16 x 16 or 8 x 16 outputs
     constexpr int BTY = 4 * BPT;
     const int Ho = (d->H - 1) / S + 1, Wo = (d->W - 1) / S + 1;
     const long long big = (long long)d->n_img * ((Ho + BTY - 1) / BTY) * ((Wo + 15) / 16);
     static const long long big_min = [] { const char* e = getenv("UAVSAL_FUSED_BIG_MIN"); return e ? atoll(e) : (long long)UAVSAL_FUSED_BIG_MIN; }();
     const bool use_big = d->tile == 2 || (d->tile == 0 && BIG_AUTO && big >= big_min);
-    return use_big ? launch_fused<CIN, HID, COUT, S, EXPAND, HCB, 16, BPT>(d, s) : launch_fused<CIN, HID, COUT, S, EXPAND, HCS, 8, 1>(d, s);
+    return use_big ? launch_fused<CIN, HID, COUT, S, EXPAND, HCB, 16, BPT>(d, s) : launch_fused<CIN, HID, COUT, S, EXPAND, HCS, 16, 1>(d, s);
 }
 
 // the channel / stride combinations that exist as instances: MobileNetV2 features[1..7] (model_feature.py:62-66)
@@ -318,7 +323,7 @@ int dispatch(const uavsal_fused_ir_desc* d, hipStream_t s, bool launch) {
     if (d->Cin == CIN && d->hidden == HID && d->Cout == COUT && d->stride == S && (d->w1 != nullptr) == EXP) \
         return launch ? launch_fused_shape<CIN, HID, COUT, S, EXP, UAVSAL_FUSED_UNPAREN HCC>(d, s) : 1;
 #ifndef UAVSAL_FUSED_HCS
-#define UAVSAL_FUSED_HCS 16       /* hidden chunk of the blocks with an expand conv, 8x8 patches */
+#define UAVSAL_FUSED_HCS 16       /* hidden chunk of the blocks with an expand conv, 4x16 patches */
 #endif
 #ifndef UAVSAL_FUSED_HCS144
 #define UAVSAL_FUSED_HCS144 16    /* ... hidden = 144 (16 or 48) */

@@ -239,7 +239,7 @@ typedef struct uavsal_fused_ir_desc {
     const float* res;  int32_t ldr;
     float*       out;  int32_t ldo;
     int32_t n_img, H, W, Cin, hidden, Cout, stride;
-    int32_t tile;                /* output patch per workgroup: 0 = by the launch size, 1 = 8x8, 2 = 16x16 (stride 1) / 8x16 (stride 2) */
+    int32_t tile;                /* output patch per workgroup: 0 = by the launch size, 1 = 4x16, 2 = 16x16 (stride 1) / 8x16 (stride 2) */
 } uavsal_fused_ir_desc;
 
 int uavsal_fused_ir(const uavsal_fused_ir_desc* d, uavsal_stream_t stream);

@@ -733,7 +733,7 @@ FUSED_CASES = [
 ]
 
 
-@pytest.mark.parametrize("tile", [1, 2])          # 8x8 patches / 16x16 (stride 1), 8x16 (stride 2)
+@pytest.mark.parametrize("tile", [1, 2])          # 4x16 patches / 16x16 (stride 1), 8x16 (stride 2)
 @pytest.mark.parametrize("case", FUSED_CASES)
 def test_fused_inverted_residual(ops, case, tile):
     n, h, w, cin, hid, cout, stride, res = case

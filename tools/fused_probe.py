@@ -51,6 +51,6 @@ if __name__ == "__main__":
             for tile in (0, 1, 2):
                 us, gbs = run(n, *b[1:], tile)
                 tot[tile] += us * (2 if b[0] == "features.5" else 1)
-                line.append("%s %7.1f us %6.0f GB/s" % ({0: "auto", 1: "8x8", 2: "big"}[tile], us, gbs))
+                line.append("%s %7.1f us %6.0f GB/s" % ({0: "auto", 1: "4x16", 2: "big"}[tile], us, gbs))
             print("n=%d %-10s %s" % (n, b[0], " | ".join(line)), flush=True)
-        print("n=%d features.1-7 sum: auto %.1f us, 8x8 %.1f us, big %.1f us" % (n, tot[0], tot[1], tot[2]), flush=True)
+        print("n=%d features.1-7 sum: auto %.1f us, 4x16 %.1f us, big %.1f us" % (n, tot[0], tot[1], tot[2]), flush=True)
