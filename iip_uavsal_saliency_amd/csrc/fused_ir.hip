@@ -66,10 +66,13 @@ struct FusedCfg : FusedGeom<S, TX, PT> {
     static constexpr int SLOTF = EXPAND ? 4 : HC + 4;
     static constexpr int EBUF = EXPAND ? (HC / 4) * PLANE : G::NRT * 16 * SLOTF;   // floats per E buffer
     static constexpr int NCH = HID / HC;
-    static constexpr int NBUF = (EXPAND && NCH > 1 && 2 * EBUF * 4 <= 78 * 1024) ? 2 : 1;   // two workgroups per CU either way
+    static constexpr int NBUF = (EXPAND && NCH > 1 && 2 * EBUF * 4 <= UAVSAL_FUSED_NBUF2_MAX) ? 2 : 1;
     static constexpr size_t SMEM = (size_t)NBUF * EBUF * 4;
 };
 
+#ifndef UAVSAL_FUSED_NBUF2_MAX
+#define UAVSAL_FUSED_NBUF2_MAX (78 * 1024)     /* two E buffers (one barrier per chunk) when they fit in this many bytes */
+#endif
 #ifndef UAVSAL_FUSED_PROBE
 #define UAVSAL_FUSED_PROBE 0      /* timing experiments only (tools/fused_probe.py): 1 no expand MFMA, 2 no depthwise taps,
                                      4 no projection MFMA, 8 every chunk uses chunk 0's weights, 16 no barriers, 32 no E writes */
