@@ -43,7 +43,7 @@ class ConvDesc(C.Structure):
                 ("a_split", _f), ("ldas", C.c_int32),
                 ("out_split", _f), ("ldos", C.c_int32),
                 ("err", _f), ("sk_spin_limit", C.c_int32), ("sk_debug_drop", C.c_int32),
-                ("w_group_stride", C.c_int64)]
+                ("w_group_stride", C.c_int64), ("n_group", C.c_int32), ("a_group_off", C.c_int32)]
 
 
 class DwDesc(C.Structure):
@@ -189,7 +189,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.uavsal_abi_version() != 14:
+    if lib.uavsal_abi_version() != 15:
         raise RuntimeError("libuavsal_hip.so ABI version mismatch")
     for i, t in enumerate(DESC_TYPES):
         if lib.uavsal_sizeof_desc(i) != C.sizeof(t):

@@ -1780,6 +1780,7 @@ int pick_tile(long long M, int Cout, int prec) {
 
 static int effective_tile(const uavsal_conv_desc* d) {
     if (d->w_group_stride) return d->tile == 11 ? 11 : 8;    // per-image weights: the instances with 32-float K stages, 128 x 128 or 64 x 64
+    if (d->n_group) return 11;                               // output-channel groups with their own inputs: the 64 x 64 instance
     int tile = (d->tile >= 1 && d->tile <= 11) ? d->tile
                                              : pick_tile((long long)d->H * d->W * d->n_img, d->Cout, d->prec);
     if (tile == 11 && !uavsal_f32_k32_eligible(d, tile)) tile = 4;
@@ -1941,6 +1942,8 @@ extern "C" int uavsal_conv_gemm(const uavsal_conv_desc* d, uavsal_stream_t strea
     k.w_gs = d->w_group_stride;
     if (k.w_gs && !((tile == 8 || tile == 11) && uavsal_f32_k32_eligible(d, tile) && d->epi == UAVSAL_EPI_AFFINE && !d->a_split))
         return UAVSAL_ESHAPE;
+    k.ngrp = d->n_group; k.a_goff = d->a_group_off;
+    if (d->n_group < 0 || (k.ngrp && !(uavsal_f32_k32_eligible(d, 11) && !d->a_split && !d->out_split))) return UAVSAL_ESHAPE;
     k.a_sp = (const _Float16*)d->a_split; k.ldas = d->ldas;
     k.out_sp = (_Float16*)d->out_split; k.ldos = d->ldos;
     if (split_eligible(d, tile)) return launch_h16(k, d->taps, tile, s);

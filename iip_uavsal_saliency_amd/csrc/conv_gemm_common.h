@@ -34,6 +34,7 @@ struct ConvK {
     _Float16* out_sp;          // optional split shadow of the output
     int ldas, ldos;            // their row strides in halves
     long long w_gs;            // per-image weights (uavsal_conv_desc.w_group_stride, floats; 0 = none): HW % 128 == 0
+    int ngrp, a_goff;          // output-channel groups with their own A columns (uavsal_conv_desc.n_group / a_group_off; 0 = none)
 };
 
 }  // namespace uavsal_gemm

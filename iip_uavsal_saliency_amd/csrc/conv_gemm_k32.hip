@@ -750,7 +750,8 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_f32_k32s_kernel(const ConvK 
             const int m = m0 + r8 + it * 32;
             const bool ok = m < p.M;
             if (TAPS == 1) {
-                a_ptr[it] = (ok ? p.a + row_off(m, p.HW, p.a_is, p.contig) * p.lda + lc * 4 : g_zero_row + lc * 4) + s0 * KT;
+                a_ptr[it] = (ok ? p.a + row_off(m, p.HW, p.a_is, p.contig) * p.lda + (p.ngrp ? (n0 / p.ngrp) * p.a_goff : 0) + lc * 4
+                                : g_zero_row + lc * 4) + s0 * KT;
             } else {
                 const int mm = ok ? m : 0;
                 const int img = mm / p.HW;
@@ -987,6 +988,9 @@ __attribute__((visibility("hidden"))) int uavsal_f32_k32_ksplit(long long tiles,
 __attribute__((visibility("hidden"))) bool uavsal_f32_k32_eligible(const uavsal_conv_desc* d, int tile) {
     if (tile < 8 || tile > 11) return false;
     if (d->w_group_stride && ((tile != 8 && tile != 11) || d->taps != 1 || (((long long)d->H * d->W) & 127))) return false;
+    if (d->n_group && (tile != 11 || d->taps != 1 || d->w_group_stride || d->epi != UAVSAL_EPI_AFFINE || (d->n_group & 63) ||
+                       d->Cout % d->n_group || d->a_group_off < d->Cin || (d->a_group_off & 3) ||
+                       (long long)d->lda < (long long)(d->Cout / d->n_group - 1) * d->a_group_off + d->Cin)) return false;
     if (d->prec != UAVSAL_PREC_F32 || d->dw_w9c || d->epi == UAVSAL_EPI_LSTM) return false;
     if (tile == 11 && d->epi == UAVSAL_EPI_TWA && ((d->ldx & 3) || (d->lda & 3) || (d->ldc & 3) || (d->Cout & 3))) return false;
     if ((d->Cin % 32) || d->Cin > UAVSAL_DWPROJ_MAX_C) return false;

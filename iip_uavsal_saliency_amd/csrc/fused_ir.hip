@@ -47,6 +47,10 @@ __device__ __forceinline__ f32x4 relu6_4(f32x4 v) {
                    __builtin_amdgcn_fmed3f(v.w, 0.f, 6.f)};
 }
 
+#ifndef UAVSAL_FUSED_NBUF2_MAX
+#define UAVSAL_FUSED_NBUF2_MAX (78 * 1024)     /* two E buffers (one barrier per chunk) when they fit in this many bytes */
+#endif
+
 template <int S, int TX, int PT>
 struct FusedGeom {
     static constexpr int RP = 16 / TX;                          // output rows per 16-pixel tile
@@ -70,9 +74,6 @@ struct FusedCfg : FusedGeom<S, TX, PT> {
     static constexpr size_t SMEM = (size_t)NBUF * EBUF * 4;
 };
 
-#ifndef UAVSAL_FUSED_NBUF2_MAX
-#define UAVSAL_FUSED_NBUF2_MAX (78 * 1024)     /* two E buffers (one barrier per chunk) when they fit in this many bytes */
-#endif
 #ifndef UAVSAL_FUSED_PROBE
 #define UAVSAL_FUSED_PROBE 0      /* timing experiments only (tools/fused_probe.py): 1 no expand MFMA, 2 no depthwise taps,
                                      4 no projection MFMA, 8 every chunk uses chunk 0's weights, 16 no barriers, 32 no E writes */

@@ -316,9 +316,11 @@ class Engine:
 
     def conv(self, name, a: V, conv, bn, out: V, act, taps=1, res: Optional[V] = None, wslice=None,
              epi=L.EPI_AFFINE, aux: Optional[V] = None, n_img=None, strides=None, cout=None,
-             out2: Optional[V] = None, gate_interleave=0, dw=None):
+             out2: Optional[V] = None, gate_interleave=0, dw=None, n_group=0):
         """`dw=(dw_conv, dw_bn, stride)`: `a` is the expanded tensor and the depthwise 3x3 + BN + ReLU6
-        is produced inside this GEMM's loader (uavsal_conv_desc.dw_*)."""
+        is produced inside this GEMM's loader (uavsal_conv_desc.dw_*).
+        `n_group`: `conv` / `bn` are lists of 1x1 convs with `n_group` outputs each whose inputs lie side by side in `a`'s rows
+        (a = the first one's view): one launch (uavsal_conv_desc.n_group / a_group_off)."""
         cin = a.c
         cout = out.c if cout is None else cout
         n_img = a.n if n_img is None else n_img
@@ -383,6 +385,7 @@ class Engine:
         d.n_img, d.H, d.W = n_img, a.h, a.w
         d.Cin, d.Cout, d.taps = cin, cout, taps
         d.prec, d.act, d.epi, d.tile = self.prec, act, epi, 0
+        d.n_group, d.a_group_off = n_group, (cin if n_group else 0)
         # GEMMs on a side lane run beside grid-filling GEMMs of the main lane: the 64 x 64 instance with 32-float K stages
         # needs 32 KB of LDS and 122 VGPRs, so one of its workgroups fits on a CU next to two of the main lane's
         # (64 KB, 155 VGPRs each) instead of waiting for them to retire
@@ -734,11 +737,24 @@ class Engine:
             hid = branches[0].hidden
             e3 = self._scr("E3", N, c5.h, c5.w, 3 * hid)
             self.conv("aspp.pw", c5, [b.conv[0][0] for b in branches], [b.conv[0][1] for b in branches], e3, R6)
-            for bi, b in enumerate(branches):
-                fork(3 + bi)
-                self.ir_block("aspp%d" % (bi + 2), c5, b, aspp.slice(256 * (bi + 1), 256), expanded=e3.slice(bi * hid, hid))
-                self.main()
+            if self.prec_name == "f32" and int(os.environ.get("UAVSAL_ASPP_GROUP", "1")) and hid % 32 == 0:
+                # ... and their three projections (1920 -> 256 each, different inputs) are ONE launch too: output-channel
+                # groups with their own A columns (uavsal_conv_desc.n_group), K shared out over workgroups
+                d3 = self._scr("D3", N, c5.h, c5.w, 3 * hid)
+                for bi, b in enumerate(branches):
+                    fork(3 + bi)
+                    self.dw("aspp%d.dw" % (bi + 2), e3.slice(bi * hid, hid), b.conv[1][0], b.conv[1][1], d3.slice(bi * hid, hid),
+                            b.stride, getattr(b, "dilation", 1))
+                    self.main()
+                aspp_grouped = d3
+            else:
+                aspp_grouped = None
+                for bi, b in enumerate(branches):
+                    fork(3 + bi)
+                    self.ir_block("aspp%d" % (bi + 2), c5, b, aspp.slice(256 * (bi + 1), 256), expanded=e3.slice(bi * hid, hid))
+                    self.main()
         else:
+            aspp_grouped = None
             for bi, b in enumerate(branches):
                 fork(3 + bi)
                 self.ir_block("aspp%d" % (bi + 2), c5, b, aspp.slice(256 * (bi + 1), 256))
@@ -752,6 +768,10 @@ class Engine:
         join(3)
         join(4)
         join(5)
+        if aspp_grouped is not None:
+            hid = branches[0].hidden
+            self.conv("aspp.pl", aspp_grouped.slice(0, hid), [b.conv[2] for b in branches], [b.conv[3] for b in branches],
+                      aspp.slice(256, 768), NONE, cout=768, n_group=256)
         self.conv("conv_lv5", aspp, sf.conv_lv5[0], sf.conv_lv5[1], x5, R6)
         self.bilinear("up_c5", x5, cat.slice(0, 256))
         join(6)

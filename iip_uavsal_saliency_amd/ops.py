@@ -69,8 +69,10 @@ def _empty_shadow(n, h, w, c, device):
 
 
 def conv_gemm(x, weight, scale=None, bias=None, act=L.ACT_NONE, res=None, out=None, prec="f32", tile=0, dw=None,
-              stream_k=False, sk_spin_limit=0, sk_debug_drop=0, split_in=False, split_out=False):
+              stream_k=False, sk_spin_limit=0, sk_debug_drop=0, split_in=False, split_out=False, n_group=0):
     """Dense 1x1 / 3x3 conv (+ folded BN, activation, residual).  `weight` [Cout,Cin,k,k] (cpu or cuda).
+    `n_group`: several 1x1 convs of different inputs as one launch -- `x` holds the inputs side by side ([.., groups * Cin]),
+    `weight` [groups * n_group, Cin, 1, 1] the stacked weights (uavsal_conv_desc.n_group / a_group_off).
     `dw=(w[C,1,3,3], scale[C], bias[C], stride)`: x is the expanded tensor and the depthwise 3x3 + BN + ReLU6
     in front of this 1x1 conv is computed inside the GEMM's loader (fused inverted-residual tail)."""
     lib = L.load()
@@ -78,11 +80,14 @@ def conv_gemm(x, weight, scale=None, bias=None, act=L.ACT_NONE, res=None, out=No
     stride = dw[3] if dw is not None else 1
     h, w = (hin - 1) // stride + 1, (win - 1) // stride + 1
     cout, taps = weight.shape[0], weight.shape[2] * weight.shape[3]
+    if n_group:
+        cin = weight.shape[1]
     if out is None:
         out = torch.empty((n, h, w, cout), dtype=torch.float32, device=x.device)
     op, ldc, *_ = _nhwc_view(out)
     keep = []
     d = L.ConvDesc()
+    d.n_group, d.a_group_off = n_group, (cin if n_group else 0)
     d.a, d.lda, d.a_img_stride = ap, lda, hin * win
     if split_in:          # pre-split A operand: the GEMM stages it by LDS-DMA (f16x3, eligible shapes)
         if not x.is_contiguous():

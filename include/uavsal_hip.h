@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define UAVSAL_ABI_VERSION 14
+#define UAVSAL_ABI_VERSION 15
 
 /* argument errors */
 #define UAVSAL_EINVAL   (-1)  /* null pointer / non-positive size */
@@ -176,6 +176,12 @@ typedef struct uavsal_conv_desc {
      * straddles two images.  This is how the sixteen GEMMs of a Winograd 3x3 convolution run as one launch
      * (uavsal_wino_input / uavsal_wino_output: the images are the sixteen transform planes). */
     int64_t w_group_stride;
+    /* Several convs of different inputs as ONE launch (F32, taps == 1, tile 11; 0 = off): output channels
+     * [g * n_group, (g + 1) * n_group) are computed from the A columns [g * a_group_off, g * a_group_off + Cin), i.e. the
+     * inputs lie side by side in the rows of `a` (lda >= groups * a_group_off) and the weight rows of the groups are stacked
+     * ([Cout][Kpad], the ordinary layout).  n_group % 64 == 0, Cout % n_group == 0.  The three dilated ASPP projections
+     * (model.py:142-147) run this way. */
+    int32_t n_group, a_group_off;
 } uavsal_conv_desc;
 
 int uavsal_conv_gemm(const uavsal_conv_desc* d, uavsal_stream_t stream);

@@ -192,6 +192,24 @@ WINO_CASES = [
     (1, 45, 80, 256, 256, 0, True), (3, 7, 5, 32, 40, 0, False), (2, 2, 3, 64, 64, 1, True), (8, 23, 40, 96, 128, 1, False)]
 
 
+@pytest.mark.parametrize("case", [(8, 12, 20, 1920, 256, 3, True), (2, 9, 13, 96, 64, 2, False), (3, 12, 20, 512, 128, 4, True)])
+def test_conv1x1_output_groups_with_their_own_inputs(ops, case):
+    """uavsal_conv_desc.n_group: the three dilated ASPP projections (model.py:142-147) as ONE launch -- group g's output
+    channels come from group g's input columns; with the workspace the K loop is shared out over workgroups."""
+    n, h, w, cin, ng, groups, ws = case
+    x = rnd((n, groups * cin, h, w), 301, 2.0)
+    wt = rnd((groups * ng, cin, 1, 1), 302, 1.0 / np.sqrt(cin))
+    scale = rnd((groups * ng,), 303) * 0.5 + 1.0
+    bias = rnd((groups * ng,), 304)
+    ref = torch.cat([F.conv2d(x[:, g * cin:(g + 1) * cin], wt[g * ng:(g + 1) * ng]) for g in range(groups)], 1)
+    ref = ref * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)
+    got = ops.conv_gemm(nhwc(x), wt, scale, bias, prec="f32", n_group=ng, stream_k=ws)
+    err = (nchw(got) - ref).abs().max().item()
+    assert err <= 3e-5 * max(1.0, ref.abs().max().item()), (case, err)
+    with pytest.raises(RuntimeError):          # groups must be whole 64-column tiles
+        ops.conv_gemm(nhwc(x), wt, scale, bias, prec="f32", n_group=ng // 2 + 8)
+
+
 @pytest.mark.parametrize("r", [2, 4])
 @pytest.mark.parametrize("case", WINO_CASES)
 def test_conv3x3_winograd(ops, case, r):
