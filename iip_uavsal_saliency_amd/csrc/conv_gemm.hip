@@ -1816,6 +1816,17 @@ static int effective_tile(const uavsal_conv_desc* d) {
             d->act != UAVSAL_ACT_SIGMOID && !(d->Cout & 3) && !(d->ldc & 3))
             tile = 11;
     }
+    // ... and the short-K expands of the small backbone maps (64 -> 384, 96 -> 576, 160 -> 960 on 23x40 / 12x20: at most one
+    // round of 64 x 64 tiles at three workgroups per CU) take it too: 9.6 / 15.9 / 11.4 us against 11.1 / 18.4 / 13.0
+    if (d->tile == 0 && tile != 11 && d->prec == UAVSAL_PREC_F32 && d->epi == UAVSAL_EPI_AFFINE && d->taps == 1) {
+        static const int k32_mode = [] { const char* e = getenv("UAVSAL_K32"); return e ? atoi(e) : 1; }();
+        static const int exp_mode = [] { const char* e = getenv("UAVSAL_K32_SMALL_EXPAND"); return e ? atoi(e) : 1; }();
+        const long long M = (long long)d->H * d->W * d->n_img;
+        const long long tiles64 = ((M + 63) / 64) * ((d->Cout + 63) / 64);
+        if (k32_mode && exp_mode && M <= 8192 && tiles64 <= 768 && d->Cout >= 256 && d->Cin >= 64 && d->Cin <= 192 &&
+            !d->w_group_stride && !d->n_group && uavsal_f32_k32_eligible(d, 11) && d->act != UAVSAL_ACT_SIGMOID && !(d->Cout & 3) && !(d->ldc & 3))
+            tile = 11;
+    }
     if (d->tile == 0 && tile == 1 && d->prec == UAVSAL_PREC_F32) {
         static const int k32_mode = [] { const char* e = getenv("UAVSAL_K32"); return e ? atoi(e) : 1; }();
         // (K of at least four 32-float stages: at K = 64 the 16-float instance is 1-2 us faster per launch -- three ring

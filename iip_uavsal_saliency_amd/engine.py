@@ -61,8 +61,10 @@ class V:
 
 
 # expanded values (pixels x hidden channels) from which the fused depthwise -> projection launch beats depthwise +
-# projection launches (tools/dwproj_probe.py: 8 x 45 x 80 x 1152 wins, 2 x 23 x 41 x 96 loses)
-FUSE_DW_MIN_WORK = 8 * 45 * 80 * 512
+# projection launches (tools/dwproj_probe.py: 2 x 23 x 41 x 96 loses).  Round 2 had 8 x 45 x 80 x 512 here, which kept the
+# 384-hidden blocks at 45x80 (temporal sub-blocks, prior nets) unfused at one clip: fused they take 29-32 us instead of 44-46
+# (one clip fp32 4.521 -> 4.452 ms, f16x3 3.25 -> 3.19)
+FUSE_DW_MIN_WORK = int(os.environ.get("UAVSAL_FUSE_DW_MIN_WORK", str(1 << 20)))
 # ... and the share of a map's 8 x 16 pixel patches that lies outside the map must be small: the kernel computes whole
 # patches (45x80: 1.07, 23x40: 1.25, 12x20: 2.13).  Eight clips, fp32, features.8-17 on the 23x40 / 12x20 maps: 1259 us fused
 # against 911 us as depthwise + projection launches (features.17 alone 282 vs 128)
