@@ -92,3 +92,15 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == UAVSAL_ACT_SIGMOID) return 1.f / (1.f + expf(-v));
     return v;
 }
+
+// Dynamic LDS above the 64 KB default is an opt-in per kernel AND per device (one process may drive several GPUs: model(x.to("cuda:1"))).
+// Placed in front of every launch of such a kernel: after the first time on a device it is one hipGetDevice and a bit test.
+#define UAVSAL_LDS_OPTIN(kernel, bytes)                                                                              \
+    do {                                                                                                             \
+        static unsigned long long uavsal_optin_done_ = 0ull;                                                         \
+        int uavsal_optin_dev_ = 0;                                                                                   \
+        if (hipGetDevice(&uavsal_optin_dev_) == hipSuccess && !((uavsal_optin_done_ >> (uavsal_optin_dev_ & 63)) & 1ull)) { \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
+            uavsal_optin_done_ |= 1ull << (uavsal_optin_dev_ & 63);                                                  \
+        }                                                                                                            \
+    } while (0)

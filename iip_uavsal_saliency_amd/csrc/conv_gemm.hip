@@ -1685,6 +1685,7 @@ int launch_dwproj_variant(const ConvK& k0, hipStream_t stream) {
     }
     k.nblk *= k.ksplit;
     const int grid = k.nblk < cap ? k.nblk : cap;
+    UAVSAL_LDS_OPTIN((dwproj_kernel<PREC, WAVES_M, WAVES_N, WM, WN>), SMEM);
     hipLaunchKernelGGL((dwproj_kernel<PREC, WAVES_M, WAVES_N, WM, WN>), dim3(grid), dim3(NT), SMEM, stream, k);
     if (k.ksplit > 1) return launch_splitk_reduce(k, PREC == UAVSAL_PREC_F16X3 ? F16X3_ACC_SCALE : 1.0f, stream);
     return uavsal_launch_status();

@@ -937,18 +937,23 @@ int launch_k32(const ConvK& k0, int taps, hipStream_t stream) {
             static const int cap9 = cap_of(conv_gemm_f32_k32p_kernel<WAVES_M, WAVES_N, 9, MINW, true>);
             const int cap = taps == 1 ? cap1 : cap9;
             const int grid = k.nblk < cap ? k.nblk : cap;
-            if (taps == 1)
+            if (taps == 1) {
+                UAVSAL_LDS_OPTIN((conv_gemm_f32_k32p_kernel<WAVES_M, WAVES_N, 1, MINW, true>), SMEM);
                 hipLaunchKernelGGL((conv_gemm_f32_k32p_kernel<WAVES_M, WAVES_N, 1, MINW, true>), dim3(grid), dim3(NT), SMEM, stream, k);
-            else
+            } else {
+                UAVSAL_LDS_OPTIN((conv_gemm_f32_k32p_kernel<WAVES_M, WAVES_N, 9, MINW, true>), SMEM);
                 hipLaunchKernelGGL((conv_gemm_f32_k32p_kernel<WAVES_M, WAVES_N, 9, MINW, true>), dim3(grid), dim3(NT), SMEM, stream, k);
+            }
             if (!k.sk_flag) { k.nblk /= k.ksplit; return launch_splitk_reduce(k, 1.0f, stream); }
         } else if (taps == 1) {
             static const int cap = cap_of(conv_gemm_f32_k32p_kernel<WAVES_M, WAVES_N, 1, MINW>);
             const int grid = k.nblk < cap ? k.nblk : cap;
+            UAVSAL_LDS_OPTIN((conv_gemm_f32_k32p_kernel<WAVES_M, WAVES_N, 1, MINW>), SMEM);
             hipLaunchKernelGGL((conv_gemm_f32_k32p_kernel<WAVES_M, WAVES_N, 1, MINW>), dim3(grid), dim3(NT), SMEM, stream, k);
         } else {
             static const int cap = cap_of(conv_gemm_f32_k32p_kernel<WAVES_M, WAVES_N, 9, MINW>);
             const int grid = k.nblk < cap ? k.nblk : cap;
+            UAVSAL_LDS_OPTIN((conv_gemm_f32_k32p_kernel<WAVES_M, WAVES_N, 9, MINW>), SMEM);
             hipLaunchKernelGGL((conv_gemm_f32_k32p_kernel<WAVES_M, WAVES_N, 9, MINW>), dim3(grid), dim3(NT), SMEM, stream, k);
         }
     } else {
@@ -962,10 +967,13 @@ int launch_k32(const ConvK& k0, int taps, hipStream_t stream) {
         k.ksplit = uavsal_f32_k32_split_ok(k) ? uavsal_f32_k32_ksplit(k.nblk, k.Kpad / 32) : 1;
         k.nblk *= k.ksplit;
         const int grid = k.nblk < cap ? k.nblk : cap;
-        if (taps == 1)
+        if (taps == 1) {
+            UAVSAL_LDS_OPTIN((conv_gemm_f32_k32_kernel<WAVES_M, WAVES_N, 1, MINW>), SMEM);
             hipLaunchKernelGGL((conv_gemm_f32_k32_kernel<WAVES_M, WAVES_N, 1, MINW>), dim3(grid), dim3(NT), SMEM, stream, k);
-        else
+        } else {
+            UAVSAL_LDS_OPTIN((conv_gemm_f32_k32_kernel<WAVES_M, WAVES_N, 9, MINW>), SMEM);
             hipLaunchKernelGGL((conv_gemm_f32_k32_kernel<WAVES_M, WAVES_N, 9, MINW>), dim3(grid), dim3(NT), SMEM, stream, k);
+        }
         if (k.ksplit > 1) return launch_splitk_reduce(k, 1.0f, stream);
     }
     return uavsal_launch_status();

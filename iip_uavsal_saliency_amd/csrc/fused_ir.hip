@@ -294,11 +294,7 @@ int launch_fused(const uavsal_fused_ir_desc* d, hipStream_t s) {
     k.tiles_x = (k.Wo + TX - 1) / TX; k.tiles_y = (k.Ho + Cfg::TY - 1) / Cfg::TY;
     const long long nblk = (long long)d->n_img * k.tiles_y * k.tiles_x;
     if (nblk > 0x7fffffffLL) return UAVSAL_ESHAPE;
-    static const int once = [] {
-        return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_ir_kernel<CIN, HID, COUT, S, EXPAND, HC, TX, PT>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::SMEM);
-    }();
-    (void)once;
+    UAVSAL_LDS_OPTIN((&fused_ir_kernel<CIN, HID, COUT, S, EXPAND, HC, TX, PT>), Cfg::SMEM);
     hipLaunchKernelGGL((fused_ir_kernel<CIN, HID, COUT, S, EXPAND, HC, TX, PT>), dim3((unsigned)nblk), dim3(256), Cfg::SMEM, s, k);
     return uavsal_launch_status();
 }
