@@ -141,6 +141,28 @@ def test_winograd_and_direct_3x3_agree_end_to_end(hip_model, golden_dir):
     assert (outs[True] - outs[False]).abs().max().item() <= 2e-4
 
 
+def test_default_fp32_plan_composition(hip_model):
+    """What DESIGN.md section 10 says about the default exact-fp32 plan at the benchmark shape (360x640, 1 clip x 8 frames),
+    pinned: no stream-K launch is left, the dense 3x3 convs are Winograd triples, the three dilated ASPP projections are one
+    grouped launch, the 384-hidden blocks at 45x80 run depthwise + projection fused, features[1..7] are one launch each, and
+    the small-map blocks (patch grid > 15 % outside the map) keep separate depthwise / projection launches."""
+    hip_model.precision = "f32"
+    eng = hip_model._engine(torch.device("cuda", torch.cuda.current_device()), 1, 8, 360, 640, "tile")
+    meta = {m["name"]: m for m in eng.ops_meta}
+    assert all(m.get("streamk", 0) == 0 for m in eng.ops_meta)
+    for nm in ("conv_last", "twa.wx", "twa.step0", "twa.step7"):
+        assert nm + ".xin" in meta and nm + ".xout" in meta and meta[nm]["tile"] == 8, nm
+    assert "aspp.pl" in meta and meta["aspp.pl"]["tile"] == 11 and meta["aspp.pl"]["Nc"] == 768 and meta["aspp.pl"]["K"] == 1920
+    assert not any(n in meta for n in ("aspp2.pl", "aspp3.pl", "aspp4.pl"))
+    for nm in ("st0.sub", "st1.sub", "gauss.1", "ob.1", "st0.sp", "fust", "fucbst", "conv_out_st"):
+        assert nm + ".dwpl" in meta and meta[nm + ".dwpl"]["dwproj"] != 0, nm
+    for i in range(1, 8):
+        assert meta["features.%d" % i]["kind"] == "fused_ir"
+    for i in (8, 12, 15, 17):
+        assert "features.%d.dw" % i in meta and "features.%d.pl" % i in meta and "features.%d.dwpl" % i not in meta
+    assert sum(1 for m in eng.ops_meta if m["kind"] != "sync") <= 130
+
+
 def make_clips(C, T, H, W, seed=0, t0=0):
     """Clip c is seeded with seed + c (oracle/make_goldens.py clip_inputs, bench.py make_clips)."""
     h, w = H // 8, W // 8
