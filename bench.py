@@ -284,6 +284,65 @@ def timed_steps(fn, steps, warmup, distributed, device):
     return dt
 
 
+def visible_gpus():
+    """GPUs this process could use, WITHOUT initialising HIP (the launcher must stay GPU-free: its children are fresh
+    processes).  `UAVSAL_BENCH_VISIBLE_GPUS` overrides the count for the CPU test of the launcher."""
+    if "UAVSAL_BENCH_VISIBLE_GPUS" in os.environ:
+        return int(os.environ["UAVSAL_BENCH_VISIBLE_GPUS"])
+    return int(torch.cuda.device_count())
+
+
+def self_launch(n, argv, worker=None, poll_s=0.2):
+    """`python bench.py --gpus N` without a launcher around it: start N fresh rank processes of this script (one per
+    GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, rendezvous on 127.0.0.1), let rank 0's JSON line
+    through on stdout, and return non-zero if any rank fails (the surviving ranks are stopped by PID: they would wait in
+    a collective for ever).  Fails loudly when fewer than N GPUs are visible -- it never measures a smaller job.
+    `worker`: the command to run per rank (default: this script with the same arguments); tests pass a stub."""
+    import socket
+    import subprocess
+    have = visible_gpus()
+    if have < n:
+        print("bench.py: --gpus %d asked for but only %d GPU(s) visible; not measuring a smaller job" % (n, have),
+              file=sys.stderr, flush=True)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = list(worker) if worker else [sys.executable, os.path.abspath(__file__)] + list(argv)
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), UAVSAL_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC only on this driver (RCCL needs it)
+        procs.append(subprocess.Popen(cmd, env=env))
+    failed = None
+    live = set(range(n))
+    while live and failed is None:
+        for r in sorted(live):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            live.discard(r)
+            if rc != 0:
+                failed = (r, rc)
+                break
+        if live and failed is None:
+            time.sleep(poll_s)
+    if failed is not None:
+        for r in sorted(live):
+            procs[r].terminate()
+        for r in sorted(live):
+            try:
+                procs[r].wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+                procs[r].wait()
+        print("bench.py: rank %d exited with code %d; %d other rank(s) stopped" % (failed[0], failed[1], len(live)),
+              file=sys.stderr, flush=True)
+        return failed[1] if 0 < failed[1] < 256 else 1
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -312,12 +371,19 @@ def main():
     ap.add_argument("--no-extra", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started the way the one-GPU bench is (no torch.distributed.run around it): become the launcher.  Nothing in
+        # this process has touched the GPU yet (device_count() does not initialise HIP on this image)
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
-    if distributed and args.gpus != world:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: refusing to measure a different job than the one asked for"
+                         % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU path to measure")
     device = torch.device("cuda", local_rank)
@@ -379,6 +445,21 @@ def main():
             "clips_per_gpu": C, "seq_len": T, "height": H, "width": W, "precision": args.prec,
             "parallelism": "clip-sharded x%d, one all-gather of maps per step" % world if distributed else "single GPU"},
     }
+
+    result["ranks_seen"] = dist.get_world_size() if distributed else 1
+    if distributed and not args.no_extra:
+        # the like-for-like origin of the weak-scaling curve, in the line itself: the SAME per-GPU workload on rank 0's GPU
+        # alone (no gather, the other ranks wait in the barrier), and value / (N x that)
+        dist.barrier()
+        if rank == 0:
+            ks = max(3, args.steps // 4)
+            dt1 = timed_steps(lambda: model.forward_clips(x, cb, state), ks, 1, False, device)
+            one = C * T * ks / dt1
+            result["scaling_reference"] = {
+                "workload": "%dx%d batch=%d clip(s) seq=%d, prec=%s on ONE GPU (rank 0 alone, other ranks idle)" % (H, W, C, T, args.prec),
+                "value": round(one, 2), "unit": "frames/s", "n_gpus": 1, "steps": ks,
+                "efficiency": round(fps / (world * one), 4)}
+        dist.barrier()
 
     if rank == 0 and world == 1:
         eng = model._engine(device, C, T, H, W, "clip", False, torch.float32)
@@ -460,7 +541,9 @@ def main():
             ks = max(3, args.steps // 4)
             dt8 = timed_steps(lambda: model.forward_clips(x8, cb8, None), ks, 1, False, device)
             result["scaling_reference"] = {"workload": "%dx%d batch=8 clip(s)/GPU seq=%d, prec=%s (what --gpus N>1 runs per GPU)" % (H, W, T, args.prec),
-                                           "value": round(8 * T * ks / dt8, 2), "unit": "frames/s", "n_gpus": 1, "steps": ks}
+                                           "value": round(8 * T * ks / dt8, 2), "unit": "frames/s", "n_gpus": 1, "steps": ks,
+                                           "note": "origin of the weak-scaling curve: an N-GPU line's efficiency is value / (N x this), "
+                                                   "NOT value / (N x this line's 1-clip value)"}
             del x8, cb8
             model.invalidate_engines()
         if not args.no_extra and args.prec == "f32":

@@ -2,9 +2,11 @@
 declares, the host packing is what the kernels document, the drop-in module tree has the
 reference's schema, errors surface as in the reference, and the clip sharding / all-gather
 layer is correct for world_size 2 over gloo."""
+import json
 import os
 import re
 import socket
+import sys
 
 import numpy as np
 import pytest
@@ -324,3 +326,81 @@ def test_mat_reader_and_priors(golden_dir):
     assert cb[0].dtype == torch.float32 and float(cb[1].max()) <= 1.0
     with pytest.raises(NotImplementedError):          # the cv2 uint8 letterbox quirk is not reproduced
         priors.get_ob_priors(os.path.join(golden_dir, "UAV2_ob_priors_train.npz"), 1, 36, 64)
+
+
+# ---- bench.py as its own launcher -----------------------------------------------
+_STUB_RANK = r'''
+import json, os, sys
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+assert os.environ["LOCAL_RANK"] == os.environ["RANK"] and os.environ["MASTER_ADDR"] == "127.0.0.1"
+assert int(os.environ["MASTER_PORT"]) > 0 and os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+open(os.path.join(sys.argv[1], "rank%d.json" % rank), "w").write(json.dumps(
+    {"rank": rank, "world": world, "port": os.environ["MASTER_PORT"], "argv": sys.argv[2:]}))
+if os.environ.get("STUB_FAIL_RANK") == str(rank):
+    sys.exit(7)
+if os.environ.get("STUB_FAIL_RANK") is not None:
+    import time
+    time.sleep(120)              # a rank stuck in a collective: the launcher must stop it
+if rank == 0:
+    print(json.dumps({"metric": "stub", "n_gpus": world}), flush=True)
+'''
+
+
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("uavsal_bench_under_test", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_bench_self_launch_starts_n_fresh_ranks(tmp_path, monkeypatch, capfd):
+    bench = _bench_module()
+    stub = tmp_path / "stub_rank.py"
+    stub.write_text(_STUB_RANK)
+    monkeypatch.setenv("UAVSAL_BENCH_VISIBLE_GPUS", "2")
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    rc = bench.self_launch(2, [], worker=[sys.executable, str(stub), str(tmp_path), "--gpus", "2"])
+    assert rc == 0
+    recs = [json.loads((tmp_path / ("rank%d.json" % r)).read_text()) for r in range(2)]
+    assert [r["rank"] for r in recs] == [0, 1] and all(r["world"] == 2 for r in recs)
+    assert recs[0]["port"] == recs[1]["port"] and recs[0]["argv"] == ["--gpus", "2"]
+    out = capfd.readouterr().out.strip().splitlines()
+    assert len(out) == 1 and json.loads(out[0]) == {"metric": "stub", "n_gpus": 2}      # rank 0's line, once
+
+
+def test_bench_self_launch_fails_loudly(tmp_path, monkeypatch, capfd):
+    bench = _bench_module()
+    stub = tmp_path / "stub_rank.py"
+    stub.write_text(_STUB_RANK)
+    # (a) a failing rank: its code is the launcher's, the rank left waiting is stopped (the call returns long before 120 s)
+    monkeypatch.setenv("UAVSAL_BENCH_VISIBLE_GPUS", "2")
+    monkeypatch.setenv("STUB_FAIL_RANK", "1")
+    import time
+    t0 = time.perf_counter()
+    rc = bench.self_launch(2, [], worker=[sys.executable, str(stub), str(tmp_path)])
+    assert rc == 7 and time.perf_counter() - t0 < 60
+    assert "rank 1 exited with code 7" in capfd.readouterr().err
+    # (b) fewer GPUs than asked for: refuse, start nothing
+    monkeypatch.delenv("STUB_FAIL_RANK")
+    monkeypatch.setenv("UAVSAL_BENCH_VISIBLE_GPUS", "1")
+    for f in tmp_path.glob("rank*.json"):
+        f.unlink()
+    assert bench.self_launch(2, [], worker=[sys.executable, str(stub), str(tmp_path)]) == 2
+    assert "only 1 GPU(s) visible" in capfd.readouterr().err and not list(tmp_path.glob("rank*.json"))
+
+
+def test_bench_gpus_2_on_a_box_without_two_gpus_exits_nonzero():
+    """The command shape the driver uses (`python bench.py --gpus N`, no launcher around it) must not silently measure one
+    GPU: in this container (no GPU) and on a 1-GPU box it exits non-zero with a message and prints no JSON line."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["UAVSAL_BENCH_VISIBLE_GPUS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "only 1 GPU(s) visible" in r.stderr and r.stdout.strip() == ""
+    # under a launcher whose world size differs from --gpus it refuses too
+    env["WORLD_SIZE"], env["RANK"], env["LOCAL_RANK"] = "1", "0", "0"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and r.stdout.strip() == ""
