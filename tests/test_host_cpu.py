@@ -324,8 +324,44 @@ def test_mat_reader_and_priors(golden_dir):
                          device="cpu")
     assert tuple(cb[0].shape) == (3, 8, 45, 80) and tuple(cb[1].shape) == (3, 20, 45, 80)
     assert cb[0].dtype == torch.float32 and float(cb[1].max()) <= 1.0
-    with pytest.raises(NotImplementedError):          # the cv2 uint8 letterbox quirk is not reproduced
-        priors.get_ob_priors(os.path.join(golden_dir, "UAV2_ob_priors_train.npz"), 1, 36, 64)
+
+
+def test_priors_resize_path_letterbox_geometry_and_uint8_truncation(golden_dir):
+    """priors stored at another size are letterboxed by `padding()` into a uint8 array
+    (reference utils_data.py:321-343, 460-464, 595-599), which truncates the [0,1] floats to {0,1}."""
+    from iip_uavsal_saliency_amd import priors
+    # hand-computed: 4x6 -> 2x3 is a scale of exactly 2, so cv2's half-pixel rule samples at 0.5, 2.5, ...: every output
+    # is the mean of a 2x2 block.  Blocks: all ones -> 1.0 (survives the uint8 cast), three ones + 0 -> 0.75 (truncated
+    # to 0), 0.5s -> 0.5 (0)
+    m = np.array([[1, 1, 1, 1, .5, .5],
+                  [1, 1, 1, 0, .5, .5],
+                  [0, 0, 1, 1, 1, 1],
+                  [0, 0, 1, 1, 1, 1]], np.float32)
+    f = priors.letterbox(m, 2, 3, quirk=False)
+    assert f.dtype == np.float32 and np.array_equal(f, np.array([[1, .75, .5], [0, 1, 1]], np.float32))
+    q = priors.letterbox(m, 2, 3)
+    assert q.dtype == np.uint8 and np.array_equal(q, np.array([[1, 0, 0], [0, 1, 1]], np.uint8))
+    # geometry, both branches of padding(): rows_rate <= cols_rate pastes full-width rows in the middle ...
+    ones = np.ones((45, 80), np.float32)
+    a = priors.letterbox(ones, 40, 64)                  # new_rows = 45 * 64 // 80 = 36, rows 2..37
+    assert a[2:38].min() == 1 and a[:2].max() == 0 and a[38:].max() == 0
+    b = priors.letterbox(ones, 36, 80)                  # rows_rate 1.25 > cols_rate 1: new_cols = 80 * 36 // 45 = 64, cols 8..71
+    assert b[:, 8:72].min() == 1 and b[:, :8].max() == 0 and b[:, 72:].max() == 0
+    # ... and the sizes BASELINE configs 0 and 4 need from the shipped 45x80 files: 36x64 and 90x160 (same aspect: no bars)
+    path = os.path.join(golden_dir, "UAV2_ob_priors_train.npz")
+    stored = np.load(path)["PriorMaps"]
+    for (r, c) in ((36, 64), (90, 160)):
+        cb = priors.get_bias([1, 1, 1], 2, r, c, ob_prior_path=path, gauss_prior_path=os.path.join(golden_dir, "gauss_priors.npz"),
+                             device="cpu")
+        assert tuple(cb[0].shape) == (2, 8, r, c) and tuple(cb[1].shape) == (2, 20, r, c) and cb[1].dtype == torch.float32
+        assert set(np.unique(cb[0].numpy())) <= {0.0, 1.0} and set(np.unique(cb[1].numpy())) <= {0.0, 1.0}     # the quirk
+        fl = priors.get_ob_priors(path, 1, r, c, quirk=False)[0]
+        assert fl.dtype == np.float32 and 0.0 <= fl.min() and fl.max() <= stored.max() + 1e-6
+        assert np.array_equal(priors.get_ob_priors(path, 1, r, c)[0], fl.astype(np.uint8))
+        assert abs(float(fl.mean()) - float(stored.mean())) < 0.02 * float(stored.mean())      # a resize, not a crop
+    # without a gaussian file the reference computes the closed form AT the requested size (utils_data.py:452-456)
+    g = priors.get_guasspriors(1, 36, 64)
+    assert g.dtype == np.float32 and g.shape == (1, 36, 64, 8) and np.array_equal(g[0], synth.gauss_priors(1, 36, 64)[0].transpose(1, 2, 0))
 
 
 # ---- bench.py as its own launcher (SURVEY.md 8(e); VERDICT round 3 item 1) -----------------------------------------------
