@@ -221,3 +221,122 @@ def loadmat(path: str) -> Dict[str, np.ndarray]:
             continue
         out[name] = arr.transpose()            # reversed dimension order -> MATLAB orientation
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Writer: the caller loop's result file (Demo_Test.py:93-95: `h5io.savemat(path, {'salmap': pred_mat})`, uint8
+# `[H, W, 1, F]`).  MATLAB v7.3 = a 512-byte text header + an HDF5 file whose datasets carry a `MATLAB_class` attribute
+# and store the array with reversed dimension order.  Written with the same structures the reader above parses (and the
+# reference's own .mat files use): superblock v0, v1 object headers, one v1 group B-tree node + local heap + symbol
+# node for the root group, contiguous data, no filters.
+_MATLAB_CLASS = {"uint8": "uint8", "int8": "int8", "uint16": "uint16", "int16": "int16", "uint32": "uint32",
+                 "int32": "int32", "uint64": "uint64", "int64": "int64", "float32": "single", "float64": "double"}
+
+
+def _pad8(b: bytes) -> bytes:
+    return b + b"\x00" * (-len(b) % 8)
+
+
+def _msg(mtype: int, data: bytes, flags: int = 0) -> bytes:
+    data = _pad8(data)
+    return struct.pack("<HHB3x", mtype, len(data), flags) + data
+
+
+def _datatype_msg(dt: np.dtype) -> bytes:
+    if dt.kind == "f":
+        if dt.itemsize == 4:        # IEEE little-endian: sign bit 31, exponent 23 / 8 bits bias 127, mantissa 0 / 23 bits
+            return bytes.fromhex("11201f00") + struct.pack("<IHHBBBBI", 4, 0, 32, 23, 8, 0, 23, 127)
+        return bytes.fromhex("11203f00") + struct.pack("<IHHBBBBI", 8, 0, 64, 52, 11, 0, 52, 1023)
+    signed = 0x08 if dt.kind == "i" else 0x00
+    return bytes([0x10, signed, 0, 0]) + struct.pack("<IHH", dt.itemsize, 0, 8 * dt.itemsize)
+
+
+def _string_attr(name: str, value: str) -> bytes:
+    """Attribute message v1: a scalar fixed-length (null-padded) ASCII string."""
+    nm = name.encode("ascii") + b"\x00"
+    val = value.encode("ascii")
+    dtype = bytes([0x13, 0x01, 0x00, 0x00]) + struct.pack("<I", len(val))       # class 3 (string), null-pad, ASCII
+    dspace = bytes([1, 0, 0, 0, 0, 0, 0, 0])                                    # v1, rank 0 (scalar)
+    return struct.pack("<BxHHH", 1, len(nm), len(dtype), len(dspace)) + _pad8(nm) + _pad8(dtype) + _pad8(dspace) + val
+
+
+def savemat(path: str, mdict: Dict[str, np.ndarray]) -> None:
+    """`hdf5storage.savemat(path, mdict)` for numeric arrays (the result writer of Demo_Test.py:93-95).  At most 8
+    variables (one symbol-table node)."""
+    names = sorted(mdict)
+    if not names or len(names) > 8:
+        raise ValueError("savemat writes 1..8 variables")
+    arrs = {}
+    for n in names:
+        a = np.asarray(mdict[n])
+        if a.dtype.name not in _MATLAB_CLASS or not n.isidentifier() or len(n) > 63:
+            raise ValueError("variable %r: unsupported dtype %s or name" % (n, a.dtype))
+        arrs[n] = a.astype(a.dtype.newbyteorder("<"), copy=False)
+    SB, BT, K_LEAF, K_INT = 96, 544, 4, 16
+    root_hdr = SB
+    btree = root_hdr + 16 + 24
+    heap = btree + BT
+    # local heap data segment: "" at 0, then the names, 8-byte aligned, then one free block
+    seg = bytearray(8)
+    name_off = {}
+    for n in names:
+        name_off[n] = len(seg)
+        seg += _pad8(n.encode("ascii") + b"\x00")
+    free_off = len(seg)
+    seg += struct.pack("<QQ", 1, 16)                       # free block: no next (1), its own size
+    heap_seg = heap + 32
+    pos = heap_seg + len(seg)
+    # dataset object headers
+    hdrs, hdr_addr, data_addr = {}, {}, {}
+    bodies = {}
+    for n in names:
+        a = arrs[n]
+        dims = a.shape[::-1] if a.ndim else ()
+        body = _msg(0x01, bytes([1, len(dims), 0, 0, 0, 0, 0, 0]) + b"".join(struct.pack("<Q", d) for d in dims))
+        body += _msg(0x03, _datatype_msg(a.dtype), flags=1)
+        body += _msg(0x05, bytes([2, 2, 0, 1]) + struct.pack("<I", 0))          # fill value v2: late allocation, default fill
+        bodies[n] = body
+        hdr_addr[n] = pos
+        pos += 16 + len(body) + 8 + 24 + len(_msg(0x0C, _string_attr("MATLAB_class", _MATLAB_CLASS[a.dtype.name])))
+    snod = pos
+    pos += 8 + 2 * K_LEAF * 40
+    for n in names:
+        data_addr[n] = pos
+        pos += (arrs[n].nbytes + 7) & ~7
+    eof = pos
+    for n in names:
+        a = arrs[n]
+        body = bodies[n] + _msg(0x08, bytes([3, 1]) + struct.pack("<QQ", data_addr[n], a.nbytes))
+        body += _msg(0x0C, _string_attr("MATLAB_class", _MATLAB_CLASS[a.dtype.name]))
+        hdrs[n] = struct.pack("<BxHII4x", 1, 5, 1, len(body)) + body
+    out = bytearray()
+    text = "MATLAB 7.3 MAT-file, Platform: iip_uavsal_saliency_amd.matio, Created on: %s HDF5 schema 1.00 ." % __import__("time").strftime("%a %b %d %H:%M:%S %Y")
+    out += text.encode("ascii")[:116].ljust(116, b" ") + bytes(8) + bytes([0x00, 0x02]) + b"IM"
+    out += bytes(512 - len(out))
+    base = 512
+    sb = bytearray(_SIG)
+    sb += bytes([0, 0, 0, 0, 0, 8, 8, 0]) + struct.pack("<HHI", K_LEAF, K_INT, 0)
+    sb += struct.pack("<QQQQ", base, _UNDEF, base + eof, _UNDEF)
+    sb += struct.pack("<QQII", 0, root_hdr, 1, 0) + struct.pack("<QQ", btree, heap)
+    assert len(sb) == SB
+    out += sb
+    out += struct.pack("<BxHII4x", 1, 1, 1, 24) + _msg(0x11, struct.pack("<QQ", btree, heap))
+    node = bytearray(b"TREE" + bytes([0, 0]) + struct.pack("<H", 1) + struct.pack("<QQ", _UNDEF, _UNDEF))
+    node += struct.pack("<QQQ", 0, snod, name_off[names[-1]])             # key 0, child 0, key 1 = the largest name
+    out += bytes(node).ljust(BT, b"\x00")
+    out += b"HEAP" + bytes(4) + struct.pack("<QQQ", len(seg), free_off, heap_seg)
+    out += seg
+    for n in names:
+        assert len(out) - base == hdr_addr[n]
+        out += hdrs[n]
+    assert len(out) - base == snod
+    sn = bytearray(b"SNOD" + bytes([1, 0]) + struct.pack("<H", len(names)))
+    for n in names:
+        sn += struct.pack("<QQII16x", name_off[n], hdr_addr[n], 0, 0)
+    out += bytes(sn).ljust(8 + 2 * K_LEAF * 40, b"\x00")
+    for n in names:
+        assert len(out) - base == data_addr[n]
+        out += _pad8(arrs[n].tobytes(order="F"))       # column-major == the transposed array in C order
+    assert len(out) - base == eof
+    with open(path, "wb") as f:
+        f.write(bytes(out))

@@ -12,20 +12,32 @@ from typing import Optional
 
 import torch
 
-from . import ops
+from . import matio, ops
+
+
+def save_salmap(path: str, sal_u8: torch.Tensor, save_frames: Optional[int] = None) -> None:
+    """The result file of the reference's loop (Demo_Test.py:92-95): `salmap` uint8 `[H, W, 1, F]` as MATLAB v7.3, the
+    first `save_frames` frames (`saveFrames`, Demo_Test.py:92).  `sal_u8`: uint8 `[F, H, W]` (what `predict_video` returns)."""
+    a = sal_u8.detach().cpu().numpy()
+    if a.dtype.name != "uint8" or a.ndim != 3:
+        raise ValueError("save_salmap takes the uint8 [F, H, W] maps of predict_video")
+    if save_frames is not None:
+        a = a[:max(0, int(save_frames))]
+    matio.savemat(path, {"salmap": a[:, :, :, None].transpose(1, 2, 3, 0)})
 
 
 @torch.no_grad()
 def predict_video(model, frames_u8: torch.Tensor, gauss_prior: torch.Tensor, ob_prior: torch.Tensor,
                   batch_size: int = 4, out_size: Optional[tuple] = None, return_maps: bool = False,
-                  persistent_state: bool = True):
+                  persistent_state: bool = True, out_path: Optional[str] = None, save_frames: Optional[int] = None):
     """`frames_u8` uint8 `[F,3,H,W]` RGB (already letterboxed to the model size, as
     preprocess_videos does, utils_data.py:255-287), `gauss_prior` `[8,h,w]`, `ob_prior` `[20,h,w]`
     float32 (one map set, repeated per frame like get_bias, Demo_Test.py:14-27).
     Frames beyond the last full `time_dims` chunk are dropped (Demo_Test.py:68-70); groups of
     `batch_size * time_dims` frames are pushed through `model.forward` with the state carried
     (Demo_Test.py:75-86).  Returns uint8 `[F', H_out, W_out]` on the device (the reference's
-    `pred_mat[..., 0]`), and the raw maps if asked."""
+    `pred_mat[..., 0]`), and the raw maps if asked; with `out_path` the maps are also written as the reference's
+    `salmap` `[H,W,1,F]` v7.3 .mat file (Demo_Test.py:93-95)."""
     dev = next(model.parameters()).device
     T = model.time_dims
     F = frames_u8.shape[0]
@@ -57,6 +69,8 @@ def predict_video(model, frames_u8: torch.Tensor, gauss_prior: torch.Tensor, ob_
         model.persistent_state = was
     maps = torch.cat(maps, 0)
     sal = ops.postprocess_predictions(maps, out_size[0], out_size[1])
+    if out_path is not None:
+        save_salmap(out_path, sal, save_frames)
     return (sal, maps) if return_maps else sal
 
 

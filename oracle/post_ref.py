@@ -2,11 +2,13 @@
 post-processing -- `postprocess_predictions` (reference utils_data.py:289-303) followed by
 `np2mat`/`im2uint8` (utils_data.py:68-82), as used at Demo_Test.py:89-91.
 
-PARITY UNPINNED for this row: the reference calls `cv2.resize` (default INTER_LINEAR), and
-OpenCV is not installed in this container, so the resize is restated from OpenCV's documented
-rule for float images (half-pixel centres, `src = (dst + 0.5) * (src_size / dst_size) - 0.5`,
-coordinates computed in double and cast to float, border replicated, horizontal pass then
-vertical pass in fp32) and has not been checked against cv2 itself.
+Pin: OpenCV is not installed in this container and the reference holds no fixture for this step, so the resize
+(`cv2.resize`, default INTER_LINEAR) is restated from OpenCV's documented rule for float images (half-pixel centres,
+`src = (dst + 0.5) * (src_size / dst_size) - 0.5`, coordinates in double cast to float, border replicated, horizontal
+pass then vertical pass in fp32).  It is pinned by known answers that follow from that rule and from the crop
+arithmetic of utils_data.py:289-303 alone (tests/post_vectors.py: linear ramps incl. clamped borders, a one-hot map's
+four weights, both crop branches), NOT by outputs of cv2 itself: a deviation of cv2's fixed-point coefficient tables
+from the documented rule would not be seen.
 """
 import numpy as np
 

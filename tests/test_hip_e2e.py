@@ -399,6 +399,18 @@ def test_postprocess_matches_numpy_restatement():
             assert got[i].max() == 255
 
 
+def test_postprocess_against_known_answers_of_the_cv2_rule():
+    """`uavsal_postprocess` against answers that need neither cv2 nor the restatement (tests/post_vectors.py): linear
+    ramps, a one-hot map, both crop branches of utils_data.py:289-303."""
+    import post_vectors
+    from iip_uavsal_saliency_amd import ops
+    for what, pred, R, Cc, exp in post_vectors.cases():
+        got = ops.postprocess_predictions(torch.from_numpy(pred)[None, None].cuda(), R, Cc).cpu().numpy()[0].astype(np.int64)
+        d = np.abs(got - np.rint(exp).astype(np.int64))
+        assert got.shape == (R, Cc) and d.max() <= 1 and (d > 0).mean() < 5e-3, (what, d.max(), (d > 0).mean())
+        assert got.max() == 255
+
+
 def test_predict_video_equals_manual_loop(hip_model, oracle):
     """The streaming driver == the reference caller's loop (Demo_Test.py:65-95) run by hand on the oracle."""
     from iip_uavsal_saliency_amd.stream import predict_video
@@ -429,6 +441,16 @@ def test_predict_video_equals_manual_loop(hip_model, oracle):
     assert (maps.cpu() - ref_maps).abs().max().item() <= MAP_TOL["f32"]
     ref0 = post_ref.to_uint8(post_ref.postprocess_predictions(ref_maps[0, 0].numpy(), H, W))
     assert np.abs(sal[0].cpu().numpy().astype(np.int32) - ref0.astype(np.int32)).max() <= 2
+    # the result file of the reference's loop (Demo_Test.py:92-95): salmap uint8 [H, W, 1, saved frames], MATLAB v7.3
+    import tempfile
+    from iip_uavsal_saliency_amd import matio
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "video.mat")
+        sal3 = predict_video(hip_model, torch.from_numpy(u8), gp, op, batch_size=2, out_path=path, save_frames=5)
+        assert torch.equal(sal3, sal)
+        mat = matio.loadmat(path)["salmap"]
+        assert mat.dtype == np.uint8 and mat.shape == (H, W, 1, 5)
+        assert np.array_equal(mat[:, :, 0, :].transpose(2, 0, 1), sal[:5].cpu().numpy())
 
 
 @pytest.mark.parametrize("prec", ["f32", "f16x3"])

@@ -135,3 +135,54 @@ def test_forward_clips_equals_independent_calls():
     o1, s1 = model(x[3:], [cb[0][3:], cb[1][3:]], None)
     assert torch.equal(out[0], o0) and torch.equal(out[1], o1)
     assert torch.equal(st[0:1], s0[0]) and torch.equal(st[1:2], s1[0])
+
+
+def test_post_ref_against_known_answers_of_the_cv2_rule():
+    """the post-processing restatement (oracle/post_ref.py) against answers that follow from cv2's
+    documented INTER_LINEAR mapping and the crop arithmetic of utils_data.py:289-303 (tests/post_vectors.py) --
+    linear ramps (exact under linear interpolation, incl. the clamped borders), a one-hot map (the four weights
+    0.25 / 0.75 / 0.75 / 0.25), one rows_rate > cols_rate and one opposite crop."""
+    import post_vectors
+    from oracle import post_ref
+    for what, pred, R, Cc, exp in post_vectors.cases():
+        got = post_ref.postprocess_predictions(pred, R, Cc)
+        assert got.shape == (R, Cc), what
+        assert np.abs(got.astype(np.float64) - exp).max() < 2e-3, (what, np.abs(got - exp).max())      # of 255
+        q = post_ref.to_uint8(got).astype(np.int64)
+        d = np.abs(q - np.rint(exp).astype(np.int64))
+        assert d.max() <= 1 and (d > 0).mean() < 5e-3, (what, d.max(), (d > 0).mean())       # .5 boundaries only
+        assert q.max() == 255
+    # the host-side resize used for the priors is the same rule
+    from iip_uavsal_saliency_amd import priors
+    pred = post_vectors.ramp_case(45, 80, 360, 640)[0]
+    assert np.array_equal(priors.resize_linear(pred, 360, 640), post_ref._resize_linear(pred, 360, 640))
+
+
+def test_mat_writer_round_trip_and_layout(tmp_path):
+    """The result file of the caller loop (Demo_Test.py:93-95): uint8 `salmap` [H,W,1,F] as MATLAB v7.3.  Round trip through
+    the reader, and the container laid out like the reference's own .mat files (512-byte MATLAB header, superblock v0 at
+    512 with base address 512, MATLAB_class attribute, reversed dimension order)."""
+    from iip_uavsal_saliency_amd import matio
+    rng = np.random.default_rng(5)
+    sal = rng.integers(0, 256, (36, 64, 1, 7), dtype=np.uint8)
+    aux = rng.standard_normal((5, 3)).astype(np.float32)
+    path = str(tmp_path / "out.mat")
+    matio.savemat(path, {"salmap": sal, "aux": aux, "d": np.arange(6.0).reshape(2, 3)})
+    got = matio.loadmat(path)
+    assert sorted(got) == ["aux", "d", "salmap"]
+    assert got["salmap"].dtype == np.uint8 and np.array_equal(got["salmap"], sal)
+    assert got["aux"].dtype == np.float32 and np.array_equal(got["aux"], aux) and np.array_equal(got["d"], np.arange(6.0).reshape(2, 3))
+    raw = open(path, "rb").read()
+    assert raw[:20] == b"MATLAB 7.3 MAT-file," and raw[124:128] == b"\x00\x02IM" and raw[512:520] == b"\x89HDF\r\n\x1a\n"
+    import struct
+    base, _, eof, _ = struct.unpack_from("<QQQQ", raw, 512 + 24)
+    assert base == 512 and eof == len(raw)
+    assert b"MATLAB_class\x00" in raw and b"uint8" in raw and b"single" in raw and b"double" in raw
+    # HDF5 stores the dimensions reversed: the dataspace of salmap is (7, 1, 64, 36) and the bytes are column-major
+    assert struct.pack("<QQQQ", 7, 1, 64, 36) in raw and sal.tobytes(order="F") in raw
+    ref = "/root/reference/gauss_priors.mat"
+    if os.path.exists(ref):      # same superblock / root-group prefix as a file hdf5storage wrote (up to the end-of-file address)
+        r = open(ref, "rb").read()
+        assert r[512:512 + 40] == raw[512:512 + 40] and r[512 + 48:512 + 96 + 40] == raw[512 + 48:512 + 96 + 40]
+    with pytest.raises(ValueError):
+        matio.savemat(path, {"x": np.zeros(3, dtype=np.complex64)})
