@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include "uavsal_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -94,13 +95,35 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 }
 
 // Dynamic LDS above the 64 KB default is an opt-in per kernel AND per device (one process may drive several GPUs: model(x.to("cuda:1"))).
-// Placed in front of every launch of such a kernel: after the first time on a device it is one hipGetDevice and a bit test.
+// Placed in front of every launch of such a kernel (all of them in functions that return a status): after the first time on
+// a device it is one hipGetDevice and a bit test.  The per-site mask is atomic (ctypes releases the GIL: two host threads may
+// launch the same kernel), a device's bit is set only once the attribute call SUCCEEDED, and a failure is returned to the
+// caller as the HIP error instead of surfacing later as a launch error.  Devices >= 64 are never memoised.
 #define UAVSAL_LDS_OPTIN(kernel, bytes)                                                                              \
     do {                                                                                                             \
-        static unsigned long long uavsal_optin_done_ = 0ull;                                                         \
+        static std::atomic<unsigned long long> uavsal_optin_done_{0ull};                                             \
         int uavsal_optin_dev_ = 0;                                                                                   \
-        if (hipGetDevice(&uavsal_optin_dev_) == hipSuccess && !((uavsal_optin_done_ >> (uavsal_optin_dev_ & 63)) & 1ull)) { \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
-            uavsal_optin_done_ |= 1ull << (uavsal_optin_dev_ & 63);                                                  \
+        hipError_t uavsal_optin_e_ = hipGetDevice(&uavsal_optin_dev_);                                               \
+        if (uavsal_optin_e_ != hipSuccess) return (int)uavsal_optin_e_;                                              \
+        const bool uavsal_optin_memo_ = uavsal_optin_dev_ >= 0 && uavsal_optin_dev_ < 64;                            \
+        if (!uavsal_optin_memo_ || !((uavsal_optin_done_.load(std::memory_order_acquire) >> uavsal_optin_dev_) & 1ull)) { \
+            uavsal_optin_e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
+            if (uavsal_optin_e_ != hipSuccess) return (int)uavsal_optin_e_;                                          \
+            if (uavsal_optin_memo_) uavsal_optin_done_.fetch_or(1ull << uavsal_optin_dev_, std::memory_order_release); \
         }                                                                                                            \
     } while (0)
+
+// A launch-time device query (resident workgroups of a kernel instance, CU count) memoised PER DEVICE: a process that
+// drives several GPUs must not size the grids / stream-K plans of device 1 from device 0's answer.  `expr` is an int > 0.
+template <typename F>
+static inline int uavsal_per_device_memo(std::atomic<int>* slots, F&& fn) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return fn();
+    int v = slots[dev].load(std::memory_order_acquire);
+    if (v <= 0) {
+        v = fn();
+        slots[dev].store(v, std::memory_order_release);
+    }
+    return v;
+}
+#define UAVSAL_PER_DEVICE(expr) ([&] { static std::atomic<int> uavsal_slots_[64]; return uavsal_per_device_memo(uavsal_slots_, [&] { return (int)(expr); }); }())

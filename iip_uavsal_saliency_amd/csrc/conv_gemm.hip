@@ -1484,14 +1484,14 @@ int launch_variant(const ConvK& k0, int taps, hipStream_t stream) {
     k.nblk = tiles_m * k.tiles_n;
     if (taps == 1 && k.dw_w) {
         if constexpr (WM * WN <= 4) {      // the fused producer is not built for the 256 x 256 tile
-            static const int cap = resident_grid(conv_gemm_kernel<PREC, WAVES_M, WAVES_N, WM, WN, 1, true>, SMEM, NT);
+            const int cap = UAVSAL_PER_DEVICE(resident_grid(conv_gemm_kernel<PREC, WAVES_M, WAVES_N, WM, WN, 1, true>, SMEM, NT));
             const int grid = k.nblk < cap ? k.nblk : cap;
             hipLaunchKernelGGL((conv_gemm_kernel<PREC, WAVES_M, WAVES_N, WM, WN, 1, true>), dim3(grid), dim3(NT), SMEM, stream, k);
         } else {
             return UAVSAL_ESHAPE;
         }
     } else if (taps == 1) {
-        static const int cap = resident_grid(conv_gemm_kernel<PREC, WAVES_M, WAVES_N, WM, WN, 1>, SMEM, NT);
+        const int cap = UAVSAL_PER_DEVICE(resident_grid(conv_gemm_kernel<PREC, WAVES_M, WAVES_N, WM, WN, 1>, SMEM, NT));
         // (same K split as the 3x3 tile below: few 64 x 64 tiles, long K -- the 1920 -> 256 ASPP projections at 12x20)
         if (WM * WN == 1 && k.kpart && k.epi == UAVSAL_EPI_AFFINE && (PREC == UAVSAL_PREC_F16X3 || PREC == UAVSAL_PREC_BF16X3)) {
             static const bool on = [] { const char* e = getenv("UAVSAL_SPLITK_1X1"); return !(e && e[0] == '0'); }();
@@ -1507,7 +1507,7 @@ int launch_variant(const ConvK& k0, int taps, hipStream_t stream) {
         hipLaunchKernelGGL((conv_gemm_kernel<PREC, WAVES_M, WAVES_N, WM, WN, 1>), dim3(grid), dim3(NT), SMEM, stream, k);
         if (k.ksplit > 1) return launch_splitk_reduce(k, PREC == UAVSAL_PREC_F16X3 ? F16X3_ACC_SCALE : 1.0f, stream);
     } else {
-        static const int cap = resident_grid(conv_gemm_kernel<PREC, WAVES_M, WAVES_N, WM, WN, 9>, SMEM, NT);
+        const int cap = UAVSAL_PER_DEVICE(resident_grid(conv_gemm_kernel<PREC, WAVES_M, WAVES_N, WM, WN, 9>, SMEM, NT));
         // 64 x 64 tile with fewer tiles than CUs-worth of slots and a long K walk (the ConvTWA step: 228 tiles x 72 K
         // steps): split K over 2 or 4 workgroups per tile; the shares' sums meet in splitk_reduce_kernel
         if (WM * WN == 1 && k.kpart && (k.epi == UAVSAL_EPI_TWA || k.epi == UAVSAL_EPI_AFFINE) &&
@@ -1562,7 +1562,7 @@ struct SkCfg {
     static constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32, SMEM = S * NKP * (BM + BN) * 64, STAGE_K = 16 * NKP;
     template <int TAPS>
     static int cap() {
-        static const int c = resident_grid(conv_gemm_f32_dma_kernel<WAVES_M, WAVES_N, WM, WN, TAPS, S, NKP, true>, SMEM);
+        const int c = UAVSAL_PER_DEVICE(resident_grid(conv_gemm_f32_dma_kernel<WAVES_M, WAVES_N, WM, WN, TAPS, S, NKP, true>, SMEM));
         return c;
     }
     template <int TAPS>
@@ -1588,11 +1588,11 @@ int launch_f32_dma(const ConvK& k0, int taps, hipStream_t stream) {
     k.tiles_n = (k.Cout + BN - 1) / BN;
     k.nblk = tiles_m * k.tiles_n;
     if (taps == 1) {
-        static const int cap = resident_grid(conv_gemm_f32_dma_kernel<WAVES_M, WAVES_N, WM, WN, 1, S, NKP>, SMEM, NT);
+        const int cap = UAVSAL_PER_DEVICE(resident_grid(conv_gemm_f32_dma_kernel<WAVES_M, WAVES_N, WM, WN, 1, S, NKP>, SMEM, NT));
         const int grid = k.nblk < cap ? k.nblk : cap;
         hipLaunchKernelGGL((conv_gemm_f32_dma_kernel<WAVES_M, WAVES_N, WM, WN, 1, S, NKP>), dim3(grid), dim3(NT), SMEM, stream, k);
     } else {
-        static const int cap = resident_grid(conv_gemm_f32_dma_kernel<WAVES_M, WAVES_N, WM, WN, 9, S, NKP>, SMEM, NT);
+        const int cap = UAVSAL_PER_DEVICE(resident_grid(conv_gemm_f32_dma_kernel<WAVES_M, WAVES_N, WM, WN, 9, S, NKP>, SMEM, NT));
         const int grid = k.nblk < cap ? k.nblk : cap;
         hipLaunchKernelGGL((conv_gemm_f32_dma_kernel<WAVES_M, WAVES_N, WM, WN, 9, S, NKP>), dim3(grid), dim3(NT), SMEM, stream, k);
     }
@@ -1640,11 +1640,11 @@ int launch_h16_dma(const ConvK& k0, int taps, hipStream_t stream) {
     k.nblk = ((k.M + BM - 1) / BM) * k.tiles_n;
 
     if (taps == 1) {
-        static const int cap = resident_grid(conv_gemm_h16_dma_kernel<WAVES_M, WAVES_N, WM, WN, 1, S>, SMEM, NT);
+        const int cap = UAVSAL_PER_DEVICE(resident_grid(conv_gemm_h16_dma_kernel<WAVES_M, WAVES_N, WM, WN, 1, S>, SMEM, NT));
         const int grid = k.nblk < cap ? k.nblk : cap;
         hipLaunchKernelGGL((conv_gemm_h16_dma_kernel<WAVES_M, WAVES_N, WM, WN, 1, S>), dim3(grid), dim3(NT), SMEM, stream, k);
     } else {
-        static const int cap = resident_grid(conv_gemm_h16_dma_kernel<WAVES_M, WAVES_N, WM, WN, 9, S>, SMEM, NT);
+        const int cap = UAVSAL_PER_DEVICE(resident_grid(conv_gemm_h16_dma_kernel<WAVES_M, WAVES_N, WM, WN, 9, S>, SMEM, NT));
         const int grid = k.nblk < cap ? k.nblk : cap;
         hipLaunchKernelGGL((conv_gemm_h16_dma_kernel<WAVES_M, WAVES_N, WM, WN, 9, S>), dim3(grid), dim3(NT), SMEM, stream, k);
     }
@@ -1665,11 +1665,8 @@ int launch_dwproj_variant(const ConvK& k0, hipStream_t stream) {
     ConvK k = k0;
     k.tiles_n = (k.Cout + BN - 1) / BN;
     k.nblk = (k.M / k.HW) * ((k.H + 7) / 8) * ((k.W + 15) / 16) * k.tiles_n;
-    static const int cap = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwproj_kernel<PREC, WAVES_M, WAVES_N, WM, WN>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-        return resident_grid(dwproj_kernel<PREC, WAVES_M, WAVES_N, WM, WN>, SMEM, NT);
-    }();
+    UAVSAL_LDS_OPTIN((dwproj_kernel<PREC, WAVES_M, WAVES_N, WM, WN>), SMEM);
+    const int cap = UAVSAL_PER_DEVICE(resident_grid(dwproj_kernel<PREC, WAVES_M, WAVES_N, WM, WN>, SMEM, NT));
     // The narrowest outputs (Cout <= 32: the 1536 -> 1 decoder projection) are bound by the serial depthwise /
     // request segments of a K step, not by the matrix pipe, and their 74 KB ring leaves room for two workgroups per
     // CU: when the tiles alone would leave resident slots empty, K is split over 2-4 workgroups per tile (raw partial
@@ -1685,7 +1682,6 @@ int launch_dwproj_variant(const ConvK& k0, hipStream_t stream) {
     }
     k.nblk *= k.ksplit;
     const int grid = k.nblk < cap ? k.nblk : cap;
-    UAVSAL_LDS_OPTIN((dwproj_kernel<PREC, WAVES_M, WAVES_N, WM, WN>), SMEM);
     hipLaunchKernelGGL((dwproj_kernel<PREC, WAVES_M, WAVES_N, WM, WN>), dim3(grid), dim3(NT), SMEM, stream, k);
     if (k.ksplit > 1) return launch_splitk_reduce(k, PREC == UAVSAL_PREC_F16X3 ? F16X3_ACC_SCALE : 1.0f, stream);
     return uavsal_launch_status();
@@ -1721,12 +1717,12 @@ int streamk_plan(const uavsal_conv_desc* d, int tile, int ktiles) {
     if (d->prec != UAVSAL_PREC_F32 || !(tile == 1 || tile == 3 || tile == 4) || d->dw_w9c ||
         d->epi == UAVSAL_EPI_LSTM || !d->sk_ws || !uavsal_aligned16(d->sk_ws))
         return 0;
-    static const int cus = [] {
+    const int cus = UAVSAL_PER_DEVICE(([] {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess ||
             hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
         return n;
-    }();
+    }()));
     const long long M = (long long)d->H * d->W * d->n_img;
     const int bm = tile == 4 ? 64 : 128, bn = tile == 1 ? 128 : (tile == 3 ? 32 : 64);
     const long long nblk = ((M + bm - 1) / bm) * ((d->Cout + bn - 1) / bn);

@@ -933,8 +933,8 @@ int launch_k32(const ConvK& k0, int taps, hipStream_t stream) {
             // UAVSAL_K32_FLAT_REDUCE=launch: the shares are summed by splitk_reduce_kernel instead
             static const bool by_launch = [] { const char* e = getenv("UAVSAL_K32_FLAT_REDUCE"); return e && e[0] == 'l'; }();
             if (by_launch) k.sk_flag = nullptr;
-            static const int cap1 = cap_of(conv_gemm_f32_k32p_kernel<WAVES_M, WAVES_N, 1, MINW, true>);
-            static const int cap9 = cap_of(conv_gemm_f32_k32p_kernel<WAVES_M, WAVES_N, 9, MINW, true>);
+            const int cap1 = UAVSAL_PER_DEVICE(cap_of(conv_gemm_f32_k32p_kernel<WAVES_M, WAVES_N, 1, MINW, true>));
+            const int cap9 = UAVSAL_PER_DEVICE(cap_of(conv_gemm_f32_k32p_kernel<WAVES_M, WAVES_N, 9, MINW, true>));
             const int cap = taps == 1 ? cap1 : cap9;
             const int grid = k.nblk < cap ? k.nblk : cap;
             if (taps == 1) {
@@ -946,19 +946,19 @@ int launch_k32(const ConvK& k0, int taps, hipStream_t stream) {
             }
             if (!k.sk_flag) { k.nblk /= k.ksplit; return launch_splitk_reduce(k, 1.0f, stream); }
         } else if (taps == 1) {
-            static const int cap = cap_of(conv_gemm_f32_k32p_kernel<WAVES_M, WAVES_N, 1, MINW>);
+            const int cap = UAVSAL_PER_DEVICE(cap_of(conv_gemm_f32_k32p_kernel<WAVES_M, WAVES_N, 1, MINW>));
             const int grid = k.nblk < cap ? k.nblk : cap;
             UAVSAL_LDS_OPTIN((conv_gemm_f32_k32p_kernel<WAVES_M, WAVES_N, 1, MINW>), SMEM);
             hipLaunchKernelGGL((conv_gemm_f32_k32p_kernel<WAVES_M, WAVES_N, 1, MINW>), dim3(grid), dim3(NT), SMEM, stream, k);
         } else {
-            static const int cap = cap_of(conv_gemm_f32_k32p_kernel<WAVES_M, WAVES_N, 9, MINW>);
+            const int cap = UAVSAL_PER_DEVICE(cap_of(conv_gemm_f32_k32p_kernel<WAVES_M, WAVES_N, 9, MINW>));
             const int grid = k.nblk < cap ? k.nblk : cap;
             UAVSAL_LDS_OPTIN((conv_gemm_f32_k32p_kernel<WAVES_M, WAVES_N, 9, MINW>), SMEM);
             hipLaunchKernelGGL((conv_gemm_f32_k32p_kernel<WAVES_M, WAVES_N, 9, MINW>), dim3(grid), dim3(NT), SMEM, stream, k);
         }
     } else {
-        static const int cap1 = cap_of(conv_gemm_f32_k32_kernel<WAVES_M, WAVES_N, 1, MINW>);
-        static const int cap9 = cap_of(conv_gemm_f32_k32_kernel<WAVES_M, WAVES_N, 9, MINW>);
+        const int cap1 = UAVSAL_PER_DEVICE(cap_of(conv_gemm_f32_k32_kernel<WAVES_M, WAVES_N, 1, MINW>));
+        const int cap9 = UAVSAL_PER_DEVICE(cap_of(conv_gemm_f32_k32_kernel<WAVES_M, WAVES_N, 9, MINW>));
         const int cap = taps == 1 ? cap1 : cap9;
         // Too few tiles for the chip and a long K walk (the ConvTWA step: 58 tiles x 72 stages; the 12x20 / 23x40 maps of
         // the backbone tail): K is split over up to 8 workgroups per tile, the shares meet in splitk_reduce_kernel
@@ -1047,15 +1047,15 @@ int launch_k32s(const ConvK& k0, int taps, hipStream_t stream) {
     };
     if (ksp > 1) {
         k.nblk *= ksp;
-        static const int cap1 = cap_of(conv_gemm_f32_k32s_kernel<1, true>);
-        static const int cap9 = cap_of(conv_gemm_f32_k32s_kernel<9, true>);
+        const int cap1 = UAVSAL_PER_DEVICE(cap_of(conv_gemm_f32_k32s_kernel<1, true>));
+        const int cap9 = UAVSAL_PER_DEVICE(cap_of(conv_gemm_f32_k32s_kernel<9, true>));
         const int cap = taps == 1 ? cap1 : cap9;
         const int grid = k.nblk < cap ? k.nblk : cap;
         if (taps == 1) hipLaunchKernelGGL((conv_gemm_f32_k32s_kernel<1, true>), dim3(grid), dim3(256), SMEM, stream, k);
         else hipLaunchKernelGGL((conv_gemm_f32_k32s_kernel<9, true>), dim3(grid), dim3(256), SMEM, stream, k);
     } else {
-        static const int cap1 = cap_of(conv_gemm_f32_k32s_kernel<1, false>);
-        static const int cap9 = cap_of(conv_gemm_f32_k32s_kernel<9, false>);
+        const int cap1 = UAVSAL_PER_DEVICE(cap_of(conv_gemm_f32_k32s_kernel<1, false>));
+        const int cap9 = UAVSAL_PER_DEVICE(cap_of(conv_gemm_f32_k32s_kernel<9, false>));
         const int cap = taps == 1 ? cap1 : cap9;
         const int grid = k.nblk < cap ? k.nblk : cap;
         if (taps == 1) hipLaunchKernelGGL((conv_gemm_f32_k32s_kernel<1, false>), dim3(grid), dim3(256), SMEM, stream, k);

@@ -7,8 +7,9 @@
 // independent GEMMs [tiles x Cin] . [Cin x Cout] -- they run as ONE launch of the ordinary fp32 GEMM with the sixteen
 // transform planes as "images" and per-image weights (uavsal_conv_desc.w_group_stride) -- so a 3x3 conv costs 2.25x
 // fewer MFMA FLOPs, which is what bounds it (the fp32 matrix rate, at the clock the chip holds: profiles/r3_gemm_k32.md),
-// for two memory-bound transform launches.  Numerics: coefficients 0, +-1, +-1/2 only; against direct fp32 convolution
-// the saliency map moves by 5e-5 (oracle experiment at 360x640, 8- and 20-frame calls: profiles/r3_winograd.md).
+// for two memory-bound transform launches.  Numerics of F(2x2): coefficients 0, +-1, +-1/2 only; against direct fp32 convolution
+// the saliency map moves by 5e-5 (oracle experiment at 360x640, 8- and 20-frame calls: profiles/r3_winograd.md).  F(4x4), which
+// the engine takes by default for the all-frames convolutions and, from four clips up, for the recurrence steps, is described below.
 //
 //   uavsal_wino_input : NHWC activation -> V[P*P][Mp][C],  V_k[tile][c] = (B^T d B)_k        one thread = (tile, 4 channels)
 //   uavsal_wino_output: M[P*P][Mp][C]   -> NHWC output,    y = A^T m A, then BN / ReLU6 / residual or the ConvTWA update
@@ -16,7 +17,9 @@
 // R = 4: 4x4 output tiles, P = 6, thirty-six planes, 4x fewer (interpolation points 0, +-1, +-2: coefficients up to 8, a
 // single conv is ~20x less accurate than direct fp32 -- 2e-5 against 1e-6 at K = 576 -- the saliency map moves by 5.3e-5).
 // tile = (image, ty, tx) in row-major order; planes are Mp rows apart (Mp % 128 == 0: every plane is whole GEMM tiles;
-// rows past the tiles are never written -- the caller zero-fills the V buffer once -- and never read back).
+// rows past the tiles are never written and never read back: the GEMM multiplies whatever the scratch holds there (GEMM rows
+// are independent, so stale -- even non-finite -- padding rows cannot reach a real output row) and the output transform only
+// reads the rows of real tiles.  The engine nevertheless zero-fills its V scratch once at allocation.
 #include "common.h"
 
 namespace {

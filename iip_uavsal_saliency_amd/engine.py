@@ -131,8 +131,13 @@ class Engine:
         self.winograd = precision == "f32" and bool(getattr(model, "winograd", True)) and os.environ.get("UAVSAL_WINOGRAD", "1") != "0"
         self.winograd_steps = int(os.environ.get("UAVSAL_WINOGRAD_STEPS", "-1"))     # -1: by the number of clips (below)
         # output tile of the transforms: 2 = F(2x2, 3x3), 4 = F(4x4, 3x3); for the all-frames convs / for the recurrence steps
-        self.winograd_r = int(os.environ.get("UAVSAL_WINOGRAD_R", "4"))
-        self.winograd_step_r = int(os.environ.get("UAVSAL_WINOGRAD_STEP_R", "0"))   # 0: by the number of clips
+        # NOTE: with the defaults the arithmetic of "exact fp32" depends on the number of clips in the call -- F(2x2) steps below
+        # four clips, F(4x4) (coefficients up to 8, ~20x less accurate per conv, map moves by ~5e-5) from four up -- so the same
+        # clip gives maps that differ by ~1e-4 when batched differently (all inside the 5e-4 gate).  `model.winograd_r = 2`
+        # (also for the steps) is the strict setting: F(2x2) everywhere, whatever the batch; `model.winograd = False`: direct.
+        self.winograd_r = int(getattr(model, "winograd_r", None) or os.environ.get("UAVSAL_WINOGRAD_R", "4"))
+        self.winograd_step_r = int(getattr(model, "winograd_step_r", None) or (2 if getattr(model, "winograd_r", None) == 2 else 0)
+                                   or os.environ.get("UAVSAL_WINOGRAD_STEP_R", "0"))   # 0: by the number of clips
         self.fuse_blocks = bool(getattr(model, "fuse_blocks", True))
         self._split_want = set()
         self._no_shadow = set()
@@ -159,8 +164,10 @@ class Engine:
         self._build()
         self._split_want -= self._no_shadow
         for k, need in self._scratch_need.items():
-            self._scratch[k] = torch.empty(max(need, 4), dtype=torch.float16 if k[0] == "Ds" else torch.float32,
-                                           device=self.device)
+            # (the Winograd V planes are zero-filled once: their padding rows are multiplied by the GEMM, never read back)
+            alloc = torch.zeros if k[0] == "WV" else torch.empty
+            self._scratch[k] = alloc(max(need, 4), dtype=torch.float16 if k[0] == "Ds" else torch.float32,
+                                     device=self.device)
         self._lane = 0
         self._dry = False
         self.ops_meta, self.stage_ranges, self.named, self._op_idx = [], {}, {}, {}
@@ -1054,8 +1061,11 @@ class Engine:
             if self.sync_errors:
                 self.check(wait=True)
             if not self._first_run_verified and self.split_mode:
-                # once per plan: a split shadow nobody wrote (see _buf) shows up as NaN in the maps
+                # once per plan (this first call is therefore synchronous even with sync_errors off): a split shadow
+                # nobody wrote (see _buf) shows up as NaN in the maps.  Device errors are raised first, under their own
+                # name: the guard's NaN fill after a stream-K time-out must not be reported as a missing shadow
                 self._first_run_verified = True
+                self.check(wait=True)
                 res = out if self.inplace else self.out
                 if bool(torch.isnan(res).any().item()) and not bool(torch.isnan(x.float()).any().item()):
                     raise RuntimeError("the first run of this plan produced NaN maps from finite frames: a split shadow "

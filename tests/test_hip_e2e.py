@@ -141,6 +141,34 @@ def test_winograd_and_direct_3x3_agree_end_to_end(hip_model, golden_dir):
     assert (outs[True] - outs[False]).abs().max().item() <= 2e-4
 
 
+def test_winograd_modes_agree_at_eight_clips(hip_model, golden_dir):
+    """From four clips up the default exact-fp32 plan switches the recurrence steps to F(4x4): default,
+    strict F(2x2) everywhere (`model.winograd_r = 2`) and direct 3x3 convs, on BASELINE configs[2]'s 8 clips x 8 frames --
+    each inside the parity bound of the reference's own maps, and within 3e-4 of each other."""
+    g = np.load(os.path.join(golden_dir, "clips_360x640_C8_T8.npz"))
+    H, W, T, C, seed, ms = int(g["H"]), int(g["W"]), int(g["T"]), int(g["C"]), int(g["seed"]), int(g["map_stride"])
+    x, cb = make_clips(C, T, H, W, seed)
+    x, cb = x.cuda(), [cb[0].cuda(), cb[1].cuda()]
+    hip_model.precision = "f32"
+    outs = {}
+    try:
+        for mode, (wino, r) in {"default": (True, None), "strict F(2x2)": (True, 2), "direct": (False, None)}.items():
+            hip_model.winograd, hip_model.winograd_r = wino, r
+            out, _ = hip_model.forward_clips(x, cb, None)
+            outs[mode] = out.cpu()
+            eng = next(reversed(hip_model._engines.values()))
+            if wino:
+                assert eng.winograd_step_r == (2 if r == 2 else 0) and eng.winograd_r == (2 if r == 2 else 4)
+            err = np.abs(outs[mode].contiguous().view(-1).numpy()[::ms] - g["out"]).max()
+            print("%s: map max-abs vs reference golden %.3e" % (mode, err))
+            assert err <= MAP_TOL["f32"], (mode, err)
+    finally:
+        hip_model.winograd, hip_model.winograd_r = True, None
+    for a in outs:
+        for b in outs:
+            assert (outs[a] - outs[b]).abs().max().item() <= 3e-4, (a, b)
+
+
 def test_default_fp32_plan_composition(hip_model):
     """What DESIGN.md section 10 says about the default exact-fp32 plan at the benchmark shape (360x640, 1 clip x 8 frames),
     pinned: no stream-K launch is left, the dense 3x3 convs are Winograd triples, the three dilated ASPP projections are one
