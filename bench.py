@@ -63,19 +63,27 @@ def kernel_symbol(prec, tile, taps, streamk=0, split=False):
     return "conv_gemm_kernel<%s>" % (H16_INST[tile] % (PREC_ID[prec], taps))
 
 
-def traffic_file(C, prec):
-    return os.path.join("profiles", "r3_hbm_traffic_%s_c%d.json" % (prec, C))
+PROFILE_ROUND = "r4"
 
 
-def inloop_file(C, prec):
-    return os.path.join("profiles", "r3_kernel_stats_%s_c%d.json" % (prec, C))
+def _wl_tag(C, T, H, W, prec):
+    """File tag of a workload's committed profile summaries: f32_c1 for the 8-frame 360x640 ones, f32_c4_720x1280_t16 otherwise."""
+    return "%s_c%d" % (prec, C) + ("" if (T, H, W) == (8, 360, 640) else "_%dx%d_t%d" % (H, W, T))
+
+
+def traffic_file(C, prec, T=8, H=360, W=640):
+    return os.path.join("profiles", "%s_hbm_traffic_%s.json" % (PROFILE_ROUND, _wl_tag(C, T, H, W, prec)))
+
+
+def inloop_file(C, prec, T=8, H=360, W=640):
+    return os.path.join("profiles", "%s_kernel_stats_%s.json" % (PROFILE_ROUND, _wl_tag(C, T, H, W, prec)))
 
 
 def _stamped(path, T, H, W):
-    """A committed profile summary, or (None, why): it must exist, be for 8-frame 360x640 clips and carry the hash of
+    """A committed profile summary, or (None, why): it must exist (one file per workload, `_wl_tag`) and carry the hash of
     the kernel sources of THIS build."""
     full = os.path.join(ROOT, path)
-    if (T, H, W) != (8, 360, 640) or not os.path.exists(full):
+    if not os.path.exists(full):
         return None, "no collection for this workload"
     blob = json.load(open(full))
     if blob.get("__stamp__", {}).get("kernel_sources_sha16") != kernel_sources_sha16():
@@ -90,7 +98,7 @@ def measured_traffic(symbol, C, T, H, W, prec):
     line (rocprofv3 wraps the process), so the file carries a stamp -- a hash of the kernel sources it was
     collected on -- and the figure is withheld (null) when the stamp does not match this build or there is no
     collection for the workload (tools/collect_profiles.sh: 1 and 8 clips in f32, 8 clips in f16x3)."""
-    src = {"file": traffic_file(C, prec), "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), FETCH x2 (gfx950)"}
+    src = {"file": traffic_file(C, prec, T, H, W), "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), FETCH x2 (gfx950)"}
     blob, why = _stamped(src["file"], T, H, W)
     src["status"] = why
     if blob is None:
@@ -107,10 +115,11 @@ def in_loop_timing(symbol, C, T, H, W, prec):
     """Average duration of the kernel instance INSIDE the timed loop (rocprofv3 --kernel-trace --stats of this bench
     command, tools/kernel_stats_report.py): lanes overlap there and kernels queue behind each other, so it differs from
     the isolated per-op hipEvent timing the `roofline` objects are computed from."""
-    blob, why = _stamped(inloop_file(C, prec), T, H, W)
+    f = inloop_file(C, prec, T, H, W)
+    blob, why = _stamped(f, T, H, W)
     if blob is None or symbol not in blob:
-        return {"status": why if blob is None else "kernel not in the summary", "file": inloop_file(C, prec)}
-    return {"status": "ok", "file": inloop_file(C, prec), "avg_launch_us": blob[symbol]["avg_us"], "calls": blob[symbol]["calls"]}
+        return {"status": why if blob is None else "kernel not in the summary", "file": f}
+    return {"status": "ok", "file": f, "avg_launch_us": blob[symbol]["avg_us"], "calls": blob[symbol]["calls"]}
 
 
 def kernel_sources_sha16():
@@ -366,6 +375,9 @@ def main():
     ap.add_argument("--fuse-blocks", type=int, default=1, help="features[1..7] as one fused launch per block (0: three launches)")
     ap.add_argument("--sync-errors", type=int, default=-1, help="-1: model default (forward_clips is asynchronous: device errors "
                     "poison the outputs and raise at the next call); 1: wait for every call's launches and raise before returning")
+    ap.add_argument("--persistent-state", type=int, default=0, help="1: BASELINE configs[4]'s mode -- the recurrent state stays in the "
+                    "engine's HBM buffer between steps (model.persistent_state) and every step continues from the previous one's state; "
+                    "0: every step gets a caller-owned state tensor (staged NCHW -> NHWC, returned as a fresh NCHW tensor)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
@@ -410,6 +422,7 @@ def main():
     model.presplit = None if args.presplit < 0 else bool(args.presplit)
     model.fuse_blocks = bool(args.fuse_blocks)
     model.sync_errors = None if args.sync_errors < 0 else bool(args.sync_errors)
+    model.persistent_state = bool(args.persistent_state)
 
     x_cpu, cb_cpu = make_clips(C, T, H, W, seed=shard.first)       # this rank's clips
     x = x_cpu.to(device)
@@ -419,7 +432,8 @@ def main():
     last = {}
 
     def step():
-        out, st = model.forward_clips(x, cb, state)
+        # persistent mode: continue from the state the previous step left in HBM (recognised by address: no copy)
+        out, st = model.forward_clips(x, cb, last.get("state", None) if args.persistent_state else state)
         if distributed:
             gather_maps(out, gathered)
         last["out"], last["state"] = out, st
@@ -443,10 +457,12 @@ def main():
         "config": {"workload": "%dx%d batch=%d clip(s)/GPU seq=%d, UAVSal.forward_clips, prec=%s, %s" % (
             H, W, C, T, args.prec, "hipGraph replay" if args.graph else "launch loop"),
             "clips_per_gpu": C, "seq_len": T, "height": H, "width": W, "precision": args.prec,
+            "persistent_state": bool(args.persistent_state),
             "parallelism": "clip-sharded x%d, one all-gather of maps per step" % world if distributed else "single GPU"},
     }
 
     result["ranks_seen"] = dist.get_world_size() if distributed else 1
+    result["peak_device_memory_mb"] = round(torch.cuda.max_memory_allocated(device) / 1e6, 1)      # weights + plan buffers + inputs
     if distributed and not args.no_extra:
         # the like-for-like origin of the weak-scaling curve, in the line itself: the SAME per-GPU workload on rank 0's GPU
         # alone (no gather, the other ranks wait in the barrier), and value / (N x that)
@@ -502,6 +518,10 @@ def main():
             result["kernel_time_ms"] = {k: round(v["ms"], 4) for k, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])}
             result["stage_time_ms"] = {k: round(eng.time_ops(a, b, 5), 4) for k, (a, b) in eng.stage_ranges.items()}
         if not args.no_cpu_baseline:
+            if args.persistent_state:       # the parity check below compares a zero-state call
+                model.persistent_state = False
+                last["out"], last["state"] = model.forward_clips(x, cb, state)
+                model.persistent_state = True
             from oracle.uavsal_ref import build_oracle       # checker / baseline only
             cores = host_cores()
             torch.set_num_threads(cores)
@@ -544,6 +564,19 @@ def main():
                                            "value": round(8 * T * ks / dt8, 2), "unit": "frames/s", "n_gpus": 1, "steps": ks,
                                            "note": "origin of the weak-scaling curve: an N-GPU line's efficiency is value / (N x this), "
                                                    "NOT value / (N x this line's 1-clip value)"}
+            if not args.no_roofline:
+                # the depthwise family (north_star: >= 60 % of the HBM roofline) on THIS leg too: at one clip its launches sit on
+                # the per-launch floor, at eight clips per GPU (what every GPU of configs[3] runs) they are bandwidth-bound
+                eng8 = model._engine(device, 8, T, H, W, "clip", False, torch.float32)
+                g8 = kernel_rooflines(eng8, args.prec, iters=3)
+                fam8 = depthwise_family(g8)
+                if fam8:
+                    fam8["workload"] = result["scaling_reference"]["workload"]
+                    fam8["share_of_kernel_time"] = round(fam8["kernel_ms_per_step"] / sum(g["ms"] for g in g8.values()), 3)
+                    result["scaling_reference"]["roofline_dw"] = fam8
+                fus8 = fused_family(g8)
+                if fus8:
+                    result["scaling_reference"]["roofline_fused"] = fus8
             del x8, cb8
             model.invalidate_engines()
         if not args.no_extra and args.prec == "f32":

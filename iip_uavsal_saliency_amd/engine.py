@@ -124,11 +124,19 @@ class Engine:
         # pass finds out which buffers are wanted (`_split_want`) and which cannot have one because a producer
         # does not write shadows (`_no_shadow`).
         presplit = getattr(model, "presplit", None)
-        self.split_mode = precision == "f16x3" and (bool(presplit) if presplit is not None else n_seq >= 4)
+        # per-layer precision (diagnostics: profiles/r4_precision.md): {op-name prefix: precision}, longest prefix wins; the
+        # GEMM of that op (and the weights packed for it) then run in that precision, everything else in the plan's
+        self.prec_overrides = dict(getattr(model, "prec_overrides", None) or {})
+        for v in self.prec_overrides.values():
+            if v not in L.PREC:
+                raise ValueError("prec_overrides: unknown precision %r" % (v,))
+        self.split_mode = (precision == "f16x3" and not self.prec_overrides
+                           and (bool(presplit) if presplit is not None else n_seq >= 4))
         # exact-fp32 mode: the dense 3x3 convs (conv_last, the ConvTWA gate conv) as Winograd F(2x2, 3x3)
         # (model.winograd, default on; UAVSAL_WINOGRAD=0 switches it off, UAVSAL_WINOGRAD_STEPS = 0 / 8 / 11: the per-step
         # convolutions of the recurrence too, with that GEMM tile)
-        self.winograd = precision == "f32" and bool(getattr(model, "winograd", True)) and os.environ.get("UAVSAL_WINOGRAD", "1") != "0"
+        self.winograd = ((precision == "f32" or bool(getattr(model, "prec_overrides", None))) and bool(getattr(model, "winograd", True))
+                         and os.environ.get("UAVSAL_WINOGRAD", "1") != "0")
         self.winograd_steps = int(os.environ.get("UAVSAL_WINOGRAD_STEPS", "-1"))     # -1: by the number of clips (below)
         # output tile of the transforms: 2 = F(2x2, 3x3), 4 = F(4x4, 3x3); for the all-frames convs / for the recurrence steps
         # NOTE: with the defaults the arithmetic of "exact fp32" depends on the number of clips in the call -- F(2x2) steps below
@@ -285,11 +293,12 @@ class Engine:
             self._wcache[key] = (self._dev(P.pad_vec(s, n, 1.0)), self._dev(P.pad_vec(b, n, 0.0)))
         return self._wcache[key]
 
-    def _convw(self, conv, sl=None, gate_interleave=0, natural=False, dwproj=False, k32=False):
+    def _convw(self, conv, sl=None, gate_interleave=0, natural=False, dwproj=False, k32=False, prec_name=None):
         """`natural`: the pre-split LDS-DMA path takes the weights as [K step][Cout][hi 32 | lo 32] ('f16x3i');
         `dwproj`: the split-fp16 depthwise -> projection kernel takes [K step of 16][Cout][hi 16 | lo 16] ('f16x3j');
         `k32`: fp32 kernels with 32-float K stages (tiles 8 / 9; differs from 'f32' for 3x3 weights only)."""
-        layout = "f16x3i" if natural else ("f16x3j" if dwproj and self.prec_name == "f16x3" else self.prec_name)
+        prec_name = prec_name or self.prec_name
+        layout = "f16x3i" if natural else ("f16x3j" if dwproj and prec_name == "f16x3" else prec_name)
         multi = isinstance(conv, (list, tuple))
         if k32 and layout == "f32" and (conv[0] if multi else conv).weight.shape[-1] == 3:
             layout = "f32k32"
@@ -303,6 +312,13 @@ class Engine:
                 w = w.reshape(4, hid, *w.shape[1:]).permute(1, 0, 2, 3, 4).reshape(4 * hid, *w.shape[1:])
             self._wcache[key] = self._dev(P.pack_conv_weight(w, layout))
         return self._wcache[key]
+
+    def _prec_for(self, name) -> str:
+        best, val = -1, self.prec_name
+        for k, v in self.prec_overrides.items():
+            if name.startswith(k) and len(k) > best:
+                best, val = len(k), v
+        return val
 
     def _tile_of(self, n_img, h, w, cout, epi) -> int:
         d = L.ConvDesc()
@@ -393,13 +409,14 @@ class Engine:
             d.aux, d.ldx, d.x_img_stride = None, 0, hw
         d.n_img, d.H, d.W = n_img, a.h, a.w
         d.Cin, d.Cout, d.taps = cin, cout, taps
-        d.prec, d.act, d.epi, d.tile = self.prec, act, epi, 0
+        pn = self._prec_for(name)
+        d.prec, d.act, d.epi, d.tile = L.PREC[pn], act, epi, 0
         d.n_group, d.a_group_off = n_group, (cin if n_group else 0)
         # GEMMs on a side lane run beside grid-filling GEMMs of the main lane: the 64 x 64 instance with 32-float K stages
         # needs 32 KB of LDS and 122 VGPRs, so one of its workgroups fits on a CU next to two of the main lane's
         # (64 KB, 155 VGPRs each) instead of waiting for them to retire
         side_tile = int(os.environ.get("UAVSAL_SIDE_TILE", "11"))      # (5.155 vs 5.17 ms per step, same box, two runs each)
-        if side_tile and self._lane != 0 and self.prec_name == "f32" and epi == L.EPI_AFFINE and dw is None and cin % 32 == 0:
+        if side_tile and self._lane != 0 and pn == "f32" and epi == L.EPI_AFFINE and dw is None and cin % 32 == 0:
             d.tile = side_tile
         if out2 is not None:
             d.out2, d.ld2 = out2.ptr, out2.ld
@@ -419,7 +436,9 @@ class Engine:
             raise RuntimeError("%s: its input only exists as a split shadow but the GEMM is not eligible" % name)
         dwproj = int(self.lib.uavsal_conv_dwproj(C.byref(d)))
         tile = int(self.lib.uavsal_conv_tile(C.byref(d)))
-        d.w = self._convw(conv, wslice, gate_interleave, natural=split, dwproj=dwproj != 0, k32=tile in (8, 9, 10, 11)).data_ptr()
+        d.w = self._convw(conv, wslice, gate_interleave, natural=split, dwproj=dwproj != 0, k32=tile in (8, 9, 10, 11),
+                          prec_name=pn).data_ptr()
+        self.ops_meta[-1]["prec"] = pn
         self.ops_meta[-1]["split"] = split
         self.ops_meta[-1]["tile"] = tile
         self.ops_meta[-1]["streamk"] = int(self.lib.uavsal_conv_streamk_grid(C.byref(d)))
@@ -461,7 +480,7 @@ class Engine:
             d.w, d.w_group_stride = self._wcache[key].data_ptr(), P.roundup(cout, 32) * P.roundup(cin, 32)
             d.out, d.ldc, d.o_img_stride = mm.ptr, cout, mp
             d.n_img, d.H, d.W, d.Cin, d.Cout, d.taps = pp, mp, 1, cin, cout, 1
-            d.prec, d.act, d.epi, d.tile = self.prec, L.ACT_NONE, L.EPI_AFFINE, gemm_tile
+            d.prec, d.act, d.epi, d.tile = L.PREC["f32"], L.ACT_NONE, L.EPI_AFFINE, gemm_tile      # Winograd plans are exact fp32
             d.err = self._err
             self.ops_meta[-1]["split"] = False
             self.ops_meta[-1]["tile"] = int(self.lib.uavsal_conv_tile(C.byref(d)))
@@ -608,7 +627,7 @@ class Engine:
             dwc, dwbn, pl, plbn = seq[0][0], seq[0][1], seq[1], seq[2]
         ho, wo = (x.h - 1) // stride + 1, (x.w - 1) // stride + 1
         if dil == 1 and blk.expand_ratio != 1 and (self.fuse_dw or (
-                self.fuse_dw is None and self.prec_name in ("f32", "f16x3") and stride == 1 and blk.hidden % 16 == 0
+                self.fuse_dw is None and self._prec_for(name + ".dwpl") in ("f32", "f16x3") and stride == 1 and blk.hidden % 16 == 0
                 and x.n * x.h * x.w * blk.hidden >= FUSE_DW_MIN_WORK and _dwproj_patch_waste(x.h, x.w) <= FUSE_DW_MAX_WASTE)):
             # depthwise computed inside the projection GEMM's loader: D never reaches HBM
             self.conv(name + ".dwpl", e, pl, plbn, out, final_act, res=x if blk.use_res_connect else None,
@@ -785,7 +804,7 @@ class Engine:
         self.bilinear("up_c5", x5, cat.slice(0, 256))
         join(6)
         x = self._buf("sfnet", N, h, w, 256)
-        if self.winograd:
+        if self.winograd and self._prec_for("conv_last") == "f32":
             self.conv3_wino("conv_last", cat, sf.conv_last[0], sf.conv_last[1], x, R6, r=self.winograd_r)
         else:
             self.conv("conv_last", cat, sf.conv_last[0], sf.conv_last[1], x, R6, taps=9)
@@ -881,7 +900,7 @@ class Engine:
             self.named["lstm_c"] = co
         else:
             pre = self._buf("twa_pre", N, h, w, 256)
-            if self.winograd:
+            if self.winograd and self._prec_for("twa.wx") == "f32":
                 self.conv3_wino("twa.wx", xf, rc, None, pre, NONE, wslice=(0, 256), r=self.winograd_r)
             else:
                 self.conv("twa.wx", xf, rc, None, pre, NONE, taps=9, wslice=(0, 256))    # W[:, :256] * x_t, all t
@@ -889,7 +908,7 @@ class Engine:
             a = h0 if t == 0 else ro.frames(t - 1, self.n_seq)
             a = V(a.t, self.n_seq, h, w, 256, 256, a.coff)
             strides = {"a": hw if t == 0 else Lq * hw, "o": Lq * hw, "r": Lq * hw, "x": Lq * hw}
-            if self.winograd and self.winograd_steps:
+            if self.winograd and self.winograd_steps and self._prec_for("twa.step") == "f32":
                 # one clip: 920 tiles of 2x2 fill the chip with 128x128 GEMM tiles; four clips and more: F(4x4) (1.78x
                 # fewer FLOPs, smaller transforms) on 64x64 tiles (measured: 4.54 vs 4.61 ms at one clip, 29.47 vs 28.80 at eight)
                 many = self.n_seq >= 4

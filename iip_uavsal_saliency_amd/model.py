@@ -170,6 +170,7 @@ class UAVSal(nn.Module):
                                         # None = from four clips up (measured: 17.71 vs 18.00 ms at eight clips, 3.240 vs 3.217 at one)
         self.fuse_blocks = True         # features[1..7]: whole inverted-residual block in one launch (uavsal_fused_ir)
         self.winograd = True            # exact-fp32 mode: dense 3x3 convs as Winograd F(4x4 / 2x2, 3x3) (csrc/winograd.hip)
+        self.prec_overrides = None      # diagnostics: {op-name prefix: precision} for single layers (engine.Engine._prec_for)
         self.winograd_r = None          # None: F(4x4) for the all-frames convs, steps F(2x2) below four clips / F(4x4) from four up
                                         # (so the fp32 result depends on how clips are batched, ~1e-4); 2: F(2x2) everywhere (strict)
         # A device-side error (a stream-K hand-off that timed out) always NaN-fills the returned map and state.
@@ -275,7 +276,8 @@ class UAVSal(nn.Module):
         key = (str(device), n_seq, seq_len, H, W, self.time_dims if ctx_mode == "tile" else seq_len,
                ctx_mode, self.precision, bool(taps), in_dtype, bool(self.use_graph), self.rnn_type, self.fuse_dw, bool(self.use_lanes),
                bool(self.stream_k), bool(self.persistent_state), tuple(getattr(self, "_sk_debug", (0, 0))),
-               self.presplit, bool(self.fuse_blocks), bool(getattr(self, "winograd", True)), getattr(self, "winograd_r", None))
+               self.presplit, bool(self.fuse_blocks), bool(getattr(self, "winograd", True)), getattr(self, "winograd_r", None),
+               tuple(sorted((getattr(self, "prec_overrides", None) or {}).items())))
         eng = self._engines.get(key)
         if eng is None:
             while len(self._engines) >= max(1, int(self.max_engines)):
