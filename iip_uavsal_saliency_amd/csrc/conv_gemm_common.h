@@ -43,6 +43,8 @@ struct ConvK {
 int uavsal_launch_f32_k32(const uavsal_gemm::ConvK& k, int taps, int tile, hipStream_t stream);
 bool uavsal_f32_k32_eligible(const uavsal_conv_desc* d, int tile);
 int uavsal_f32_k32_ksplit(long long tiles, int stages);
+// dwproj.hip: depthwise 3x3 + BN + ReLU6 -> 1x1 projection in one launch (LDS halo tile), fp32 / split-fp16
+int uavsal_launch_dwproj(const uavsal_gemm::ConvK& k, int prec, hipStream_t stream);
 
 namespace {
 using uavsal_gemm::ConvK;
@@ -295,6 +297,19 @@ int launch_splitk_reduce(const ConvK& k, float acc_scale, hipStream_t stream) {
     const long long items = (long long)k.M * ((k.Cout + 3) / 4);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream, k, acc_scale);
     return uavsal_launch_status();
+}
+
+#define UAVSAL_SPLIT_REF_SLOTS 512          /* dwproj_kernel's narrow instance: two workgroups per CU */
+#define UAVSAL_SPLIT_REF_SLOTS_64 1024      /* the register-staged 64 x 64 tiles (32 KB of LDS): four per CU */
+
+// resident workgroups per CU for one kernel instantiation (cached; queried once, outside any capture)
+template <typename K>
+int resident_grid(K kernel, int smem, int threads = 256) {
+    int per_cu = 0, cus = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, smem) != hipSuccess || per_cu <= 0) per_cu = 1;
+    return per_cu * cus;
 }
 
 }  // namespace
