@@ -12,7 +12,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 INCLUDE = os.path.join(ROOT, "include")
 LIB = os.path.join(PKG, "libuavsal_hip.so")
-SOURCES = ["conv_gemm.hip", "conv_gemm_k32.hip", "dwproj.hip", "dw_conv.hip", "fused_ir.hip", "glue.hip", "post.hip", "plan.hip", "winograd.hip"]
+SOURCES = ["conv_gemm.hip", "conv_gemm_k32.hip", "dwproj.hip", "dw_conv.hip", "fused_ir.hip", "fused_mid.hip", "glue.hip", "post.hip", "plan.hip", "winograd.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC]
 FLAGS += os.environ.get("UAVSAL_EXTRA_HIPCC_FLAGS", "").split()        # e.g. -DUAVSAL_PROBE for tools/gemm_probe2.py
 

@@ -346,9 +346,13 @@ int dispatch(const uavsal_fused_ir_desc* d, hipStream_t s, bool launch) {
 
 }  // namespace
 
+// fused_mid.hip: the GEMM-shaped kernel for the mid-channel blocks (Cin 64 / 96); 2 = instance exists
+int uavsal_fused_mid_dispatch(const uavsal_fused_ir_desc* d, hipStream_t s, bool launch);
+
 extern "C" int uavsal_fused_ir_supported(const uavsal_fused_ir_desc* d) {
     if (!d) return 0;
-    return dispatch(d, nullptr, false);
+    const int mid = uavsal_fused_mid_dispatch(d, nullptr, false);
+    return mid ? mid : dispatch(d, nullptr, false);
 }
 
 extern "C" int uavsal_fused_ir(const uavsal_fused_ir_desc* d, uavsal_stream_t stream) {
@@ -362,5 +366,9 @@ extern "C" int uavsal_fused_ir(const uavsal_fused_ir_desc* d, uavsal_stream_t st
         return UAVSAL_EALIGN;
     if (d->tile < 0 || d->tile > 2) return UAVSAL_EINVAL;
     if (d->res && (d->ldr < d->Cout || d->stride != 1 || d->Cin != d->Cout)) return UAVSAL_ESHAPE;
+    if (uavsal_fused_mid_dispatch(d, nullptr, false)) {
+        if (!uavsal_aligned16(d->w1) || !uavsal_aligned16(d->w2)) return UAVSAL_EALIGN;      // staged by 16-byte LDS-DMA requests
+        return uavsal_fused_mid_dispatch(d, (hipStream_t)stream, true);
+    }
     return dispatch(d, (hipStream_t)stream, true);
 }

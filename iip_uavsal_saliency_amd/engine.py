@@ -71,6 +71,11 @@ FUSE_DW_MIN_WORK = int(os.environ.get("UAVSAL_FUSE_DW_MIN_WORK", str(1 << 20)))
 FUSE_DW_MAX_WASTE = float(os.environ.get("UAVSAL_FUSE_DW_MAX_WASTE", "1.15"))
 
 
+# the mid-channel fused block kernel (csrc/fused_mid.hip): workgroups (4 x 8 output patches) of a launch for which it is taken
+MID_MIN_WGS = int(os.environ.get("UAVSAL_MID_MIN_WGS", "1"))
+MID_MAX_WGS = int(os.environ.get("UAVSAL_MID_MAX_WGS", "512"))
+
+
 def _dwproj_patch_waste(h, w):
     return ((h + 7) // 8 * 8) * ((w + 15) // 16 * 16) / float(h * w)
 
@@ -564,10 +569,19 @@ class Engine:
         d = L.FusedIrDesc()
         d.Cin, d.hidden, d.Cout, d.stride = x.c, blk.hidden, out.c, blk.stride
         d.w1 = (1 << 20) if blk.expand_ratio != 1 else None
-        if not int(self.lib.uavsal_fused_ir_supported(C.byref(d))):
+        kind = int(self.lib.uavsal_fused_ir_supported(C.byref(d)))
+        if not kind:
             return False
+        natural = kind == 2          # csrc/fused_mid.hip: 1x1 weights in their own layout
+        if natural:
+            # one workgroup per 4 x 8 output patch and CU-wide LDS: taken where the launch is about one round of the chip
+            # (the 23x40 backbone maps at one clip); bigger launches keep expand GEMM + depthwise / projection launches
+            wgs = x.n * ((x.h + 3) // 4) * ((x.w + 7) // 8)
+            if not (MID_MIN_WGS <= wgs <= MID_MAX_WGS):
+                return False
         ho, wo = (x.h - 1) // blk.stride + 1, (x.w - 1) // blk.stride + 1
-        self._meta(kind="fused_ir", name=name, kernel="fused_ir_kernel<%d, %d, %d, %d>" % (x.c, blk.hidden, out.c, blk.stride),
+        self._meta(kind="fused_ir", name=name, kernel="%s<%d, %d, %d%s>" % ("fused_mid_kernel" if natural else "fused_ir_kernel", x.c, blk.hidden, out.c,
+                                                                    "" if natural else ", %d" % blk.stride),
                    flops=2.0 * x.n * ((x.h * x.w * x.c * blk.hidden if blk.expand_ratio != 1 else 0)
                                       + ho * wo * blk.hidden * (9 + out.c)),
                    bytes=4.0 * x.n * (x.h * x.w * x.c + ho * wo * out.c * (2 if blk.use_res_connect else 1)),
@@ -581,17 +595,19 @@ class Engine:
             pw, pwbn, dwc, dwbn, pl, plbn = seq[0][0], seq[0][1], seq[1][0], seq[1][1], seq[2], seq[3]
         else:
             pw, pwbn, dwc, dwbn, pl, plbn = None, None, seq[0][0], seq[0][1], seq[1], seq[2]
-        key = ("fused", id(dwc))
+        key = ("fused", id(dwc), natural)
         if key not in self._wcache:
             ws = {}
             if pw is not None:
                 s_, b_ = P.fold_bn(pwbn)
-                ws["w1"] = self._dev(pw.weight.detach().float().cpu().reshape(blk.hidden, x.c).t().contiguous())
+                w1 = pw.weight.detach().float().cpu().reshape(blk.hidden, x.c)
+                ws["w1"] = self._dev((w1 if natural else w1.t()).contiguous())
                 ws["s1"], ws["b1"] = self._dev(s_), self._dev(b_)
             s_, b_ = P.fold_bn(dwbn)
             ws["wd"], ws["sd"], ws["bd"] = self._dev(P.pack_dw_weight(dwc.weight)), self._dev(s_), self._dev(b_)
             s_, b_ = P.fold_bn(plbn)
-            ws["w2"] = self._dev(pl.weight.detach().float().cpu().reshape(out.c, blk.hidden).t().contiguous())
+            w2 = pl.weight.detach().float().cpu().reshape(out.c, blk.hidden)
+            ws["w2"] = self._dev((w2 if natural else w2.t()).contiguous())
             ws["s2"], ws["b2"] = self._dev(s_), self._dev(b_)
             self._wcache[key] = ws
         ws = self._wcache[key]

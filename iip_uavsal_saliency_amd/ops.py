@@ -261,17 +261,20 @@ def fused_ir(x, w1, bn1, wd, bnd, w2, bn2, stride=1, residual=False, tile=0):
         return t.data_ptr()
     d = L.FusedIrDesc()
     d.inp, d.ldi = ip, ldi
+    d.n_img, d.H, d.W, d.Cin, d.hidden, d.Cout, d.stride, d.tile = n, h, w, cin, hid, cout, stride, tile
+    d.w1 = (1 << 20) if w1 is not None else None
+    kind = int(lib.uavsal_fused_ir_supported(C.byref(d)))
+    if not kind:
+        raise RuntimeError("no fused inverted-residual instance for (Cin, hidden, Cout, stride) = %s" % ((cin, hid, cout, stride),))
+    natural = kind == 2          # the mid-channel kernel takes the 1x1 weights in their own layout, the small-channel one transposed
     if w1 is not None:
-        d.w1 = up(w1.reshape(hid, cin).t())
+        d.w1 = up(w1.reshape(hid, cin) if natural else w1.reshape(hid, cin).t())
         d.scale1, d.bias1 = up(bn1[0]), up(bn1[1])
     d.wd, d.scale_d, d.bias_d = up(P.pack_dw_weight(wd)), up(bnd[0]), up(bnd[1])
-    d.w2, d.scale2, d.bias2 = up(w2.reshape(cout, hid).t()), up(bn2[0]), up(bn2[1])
+    d.w2, d.scale2, d.bias2 = up(w2.reshape(cout, hid) if natural else w2.reshape(cout, hid).t()), up(bn2[0]), up(bn2[1])
     if residual:
         d.res, d.ldr = ip, ldi
     d.out, d.ldo = out.data_ptr(), cout
-    d.n_img, d.H, d.W, d.Cin, d.hidden, d.Cout, d.stride, d.tile = n, h, w, cin, hid, cout, stride, tile
-    if not int(lib.uavsal_fused_ir_supported(C.byref(d))):
-        raise RuntimeError("no fused inverted-residual instance for (Cin, hidden, Cout, stride) = %s" % ((cin, hid, cout, stride),))
     L.check(lib.uavsal_fused_ir(C.byref(d), _stream(x)), "uavsal_fused_ir")
     torch.cuda.current_stream(dev).synchronize()
     return out

@@ -249,7 +249,11 @@ typedef struct uavsal_fused_ir_desc {
 } uavsal_fused_ir_desc;
 
 int uavsal_fused_ir(const uavsal_fused_ir_desc* d, uavsal_stream_t stream);
-int uavsal_fused_ir_supported(const uavsal_fused_ir_desc* d);     /* 1 / 0; no launch */
+/* 0: no instance.  1: an instance of the small-channel kernel (features[1..7]); w1 is [Cin][hidden], w2 [hidden][Cout]
+ * (the 1x1 weights transposed).  2: an instance of the mid-channel kernel (csrc/fused_mid.hip: stride 1, (Cin, hidden, Cout)
+ * in {(64,384,64), (64,384,96), (64,384,32), (96,576,96)}); w1 is [hidden][Cin], w2 [Cout][hidden] -- the conv weights' own
+ * layout -- 16-byte aligned.  No launch. */
+int uavsal_fused_ir_supported(const uavsal_fused_ir_desc* d);
 
 /*
  * Stem: dense 3x3 stride-2 pad-1 convolution 3 -> 32 + BatchNorm + ReLU6 reading the

@@ -3,7 +3,11 @@
 Checked against (a) the oracle (oracle/uavsal_ref.py, torch-CPU fp32 restatement) on the same
 seeded inputs and (b) the committed golden vectors that oracle/make_goldens.py produced by
 running the reference's own model.py.  Tolerance on the fp32 saliency map: 1e-3 max-abs
-(BASELINE.json north_star); the exact-fp32 MFMA mode is held to 1e-4.
+(BASELINE.json north_star); the two SUPPORTED modes -- exact-fp32 MFMA (`f32`, the headline) and the
+3 x fp16 split (`f16x3`) -- are gated at 5e-4 on every golden.  `bf16x3` and `bf16` are diagnostics:
+they are NOT parity modes (bf16x3 misses 1e-3 at 360x640: 1.15e-3; single-pass bf16, the literal
+reading of BASELINE configs[2], misses it by 300x: profiles/r4_precision.md) and the bounds they are
+held to here are regression bounds, not claims.
 """
 import os
 
@@ -17,9 +21,12 @@ pytestmark = pytest.mark.gpu
 
 # The synthetic network amplifies fp32 round-off by ~10^3 (two exact-fp32 implementations that
 # only differ in summation order -- this one and oneDNN -- end 1.5e-4 apart on the 360x640 map),
-# so the fp32-class modes are held to 5e-4, half the 1e-3 of the north_star; the 16-bit split
-# `bf16x3` sits right at 1e-3 on the largest case and is reported, not gated, there.
+# so the fp32-class modes are held to 5e-4, half the 1e-3 of the north_star.  `bf16x3` (diagnostic, see the
+# module docstring) is bounded at 2e-3: a regression bound ABOVE the north_star's tolerance, not a parity claim.
+NORTH_STAR_TOL = 1e-3
+PARITY_PRECS = ["f32", "f16x3"]            # the modes the package claims; every golden, <= 5e-4
 MAP_TOL = {"f32": 5e-4, "f16x3": 5e-4, "bf16x3": 2e-3}
+assert all(MAP_TOL[p_] <= NORTH_STAR_TOL for p_ in PARITY_PRECS)
 LOGIT_TOL = {"f32": 2e-3, "f16x3": 2e-3, "bf16x3": 1.5e-2}     # logits span about +-12
 STATE_TOL = {"f32": 5e-4, "f16x3": 5e-4, "bf16x3": 4e-3}
 TAP_REL = {"f32": 1e-4, "f16x3": 1e-4, "bf16x3": 1e-3}        # relative to max|tap|
@@ -185,10 +192,16 @@ def test_default_fp32_plan_composition(hip_model):
     for nm in ("st0.sub", "st1.sub", "gauss.1", "ob.1", "st0.sp", "fust", "fucbst", "conv_out_st"):
         assert nm + ".dwpl" in meta and meta[nm + ".dwpl"]["dwproj"] != 0, nm
     for i in range(1, 8):
-        assert meta["features.%d" % i]["kind"] == "fused_ir"
-    for i in (8, 12, 15, 17):
+        assert meta["features.%d" % i]["kind"] == "fused_ir" and meta["features.%d" % i]["kernel"].startswith("fused_ir_kernel")
+    # round 4: the stride-1 blocks of the 23x40 map (features.8-13: 240 workgroups of the mid-channel kernel) are one launch each
+    for i in range(8, 14):
+        assert meta["features.%d" % i]["kind"] == "fused_ir" and meta["features.%d" % i]["kernel"].startswith("fused_mid_kernel")
+    for i in (14, 15, 17):       # stride 2 / the 12x20 map: three launches
         assert "features.%d.dw" % i in meta and "features.%d.pl" % i in meta and "features.%d.dwpl" % i not in meta
-    assert sum(1 for m in eng.ops_meta if m["kind"] != "sync") <= 130
+    # ... and the same block shapes at 45x80 (960 workgroups: several rounds of the chip) keep their GEMM + fused dw/projection launches
+    for nm in ("gauss.1", "st0.sub"):
+        assert nm + ".pw" in meta and nm + ".dwpl" in meta
+    assert sum(1 for m in eng.ops_meta if m["kind"] != "sync") <= 118
 
 
 def make_clips(C, T, H, W, seed=0, t0=0):
@@ -331,6 +344,27 @@ def test_bf16_single_pass_error_is_reported(hip_model, oracle):
     err = (ho - ro).abs().max().item()
     print("bf16 single-pass max-abs on the map: %.3e" % err)
     assert err <= 0.5
+
+
+def test_diagnostic_precisions_on_the_eight_clip_golden(hip_model, golden_dir):
+    """`bf16x3` and single-pass `bf16` on BASELINE configs[2]'s shape (8 clips x 8 frames, 360x640) against the
+    reference's own maps: reported, bounded (regression bounds), and explicitly NOT inside the north_star's 1e-3 --
+    configs[2]'s literal "bf16" is not delivered; `f16x3` (test_forward_clips_vs_reference_golden) is what stands in."""
+    g = np.load(os.path.join(golden_dir, "clips_360x640_C8_T8.npz"))
+    H, W, T, C, seed, ms = int(g["H"]), int(g["W"]), int(g["T"]), int(g["C"]), int(g["seed"]), int(g["map_stride"])
+    x, cb = make_clips(C, T, H, W, seed)
+    x, cb = x.cuda(), [cb[0].cuda(), cb[1].cuda()]
+    errs = {}
+    try:
+        for prec in ("bf16x3", "bf16"):
+            hip_model.precision = prec
+            out, _ = hip_model.forward_clips(x, cb, None)
+            errs[prec] = float(np.abs(out.cpu().contiguous().view(-1).numpy()[::ms] - g["out"]).max())
+            print("%s on clips_360x640_C8_T8: map max-abs vs the reference %.3e" % (prec, errs[prec]))
+    finally:
+        hip_model.precision = "f32"
+    assert errs["bf16x3"] <= MAP_TOL["bf16x3"]          # regression bound (2e-3), above the 1e-3 tolerance
+    assert NORTH_STAR_TOL < errs["bf16"] <= 0.5          # single-pass bf16 does not meet 1e-3: keep that visible
 
 
 @pytest.mark.parametrize("prec", PRECS)

@@ -774,7 +774,41 @@ def test_fused_inverted_residual(ops, case, tile):
 
 
 def test_fused_inverted_residual_rejects_other_shapes(ops):
-    x = nhwc(rnd((1, 64, 9, 13), 111))
+    x = nhwc(rnd((1, 128, 9, 13), 111))
     with pytest.raises(RuntimeError):
-        ops.fused_ir(x, rnd((384, 64, 1, 1), 1), (torch.ones(384), torch.zeros(384)), rnd((384, 1, 3, 3), 2),
-                     (torch.ones(384), torch.zeros(384)), rnd((64, 384, 1, 1), 3), (torch.ones(64), torch.zeros(64)))
+        ops.fused_ir(x, rnd((768, 128, 1, 1), 1), (torch.ones(768), torch.zeros(768)), rnd((768, 1, 3, 3), 2),
+                     (torch.ones(768), torch.zeros(768)), rnd((128, 768, 1, 1), 3), (torch.ones(128), torch.zeros(128)))
+    with pytest.raises(RuntimeError):          # the mid-channel kernel (csrc/fused_mid.hip) is stride 1 only
+        ops.fused_ir(nhwc(rnd((1, 64, 9, 13), 112)), rnd((384, 64, 1, 1), 1), (torch.ones(384), torch.zeros(384)), rnd((384, 1, 3, 3), 2),
+                     (torch.ones(384), torch.zeros(384)), rnd((64, 384, 1, 1), 3), (torch.ones(64), torch.zeros(64)), stride=2)
+
+
+# ---- mid-channel fused block (csrc/fused_mid.hip): features[8..13], the second prior-net block, the temporal sub-block ----
+MID_CASES = [   # (n, h, w, cin, hidden, cout): maps that are / are not multiples of the 4 x 8 patch, tiny maps
+    (2, 23, 40, 64, 384, 64), (1, 12, 20, 64, 384, 96), (2, 23, 40, 96, 576, 96), (1, 9, 13, 64, 384, 32),
+    (3, 4, 8, 64, 384, 64), (1, 5, 9, 96, 576, 96), (1, 1, 1, 64, 384, 64), (1, 45, 80, 64, 384, 32),
+]
+
+
+@pytest.mark.parametrize("case", MID_CASES)
+def test_fused_mid_channel_block(ops, case):
+    """One launch == pw-expand + BN + ReLU6 -> dw3x3 + BN + ReLU6 -> pw-linear + BN [+ x] (reference model.py:74-103;
+    torchvision InvertedResidual), exact fp32, against torch-CPU fp32."""
+    n, h, w, cin, hid, cout = case
+    x = rnd((n, cin, h, w), 201, 2.0)
+    bn = lambda c, s: (rnd((c,), s) * 0.5 + 1.0, rnd((c,), s + 1))
+    w1 = rnd((hid, cin, 1, 1), 202, 1.0 / np.sqrt(cin))
+    wd = rnd((hid, 1, 3, 3), 203, 0.4)
+    w2 = rnd((cout, hid, 1, 1), 204, 1.0 / np.sqrt(hid))
+    b1, bd, b2 = bn(hid, 205), bn(hid, 207), bn(cout, 209)
+    aff = lambda y, b: y * b[0].view(1, -1, 1, 1) + b[1].view(1, -1, 1, 1)
+    e = torch.clamp(aff(F.conv2d(x, w1), b1), 0, 6)
+    dd = torch.clamp(aff(F.conv2d(e, wd, padding=1, groups=hid), bd), 0, 6)
+    ref = aff(F.conv2d(dd, w2), b2)
+    res = cin == cout
+    if res:
+        ref = ref + x
+    got = ops.fused_ir(nhwc(x), w1, b1, wd, bd, w2, b2, stride=1, residual=res)
+    assert tuple(got.shape) == (n, h, w, cout)
+    err = (nchw(got) - ref).abs().max().item()
+    assert err <= 2e-5 * max(1.0, ref.abs().max().item()), (case, err)

@@ -9,7 +9,7 @@ mkdir -p $R/tools/_tmp
 FLAGS="-O3 --offload-arch=gfx950 -std=c++17 -fPIC -I$R/include -I$C"
 SRC=${SRC:-conv_gemm_k32}
 OTHERS=""
-for o in conv_gemm conv_gemm_k32 dwproj dw_conv fused_ir glue post plan winograd; do [ $o = $SRC ] || OTHERS="$OTHERS $C/$o.o"; done
+for o in conv_gemm conv_gemm_k32 dwproj dw_conv fused_ir fused_mid glue post plan winograd; do [ $o = $SRC ] || OTHERS="$OTHERS $C/$o.o"; done
 VARIANTS=${VARIANTS:-"probe:-DUAVSAL_PROBE stamps:-DUAVSAL_K32_STAMPS"}
 for v in $VARIANTS; do
   name=${v%%:*}; defs=$(echo ${v#*:} | tr ',' ' ')
