@@ -247,11 +247,15 @@ def fused_family(groups):
     byts = sum(g["bytes"] for g in fu.values())
     ms = sum(g["ms"] for g in fu.values())
     fl = sum(g["flops"] for g in fu.values())
-    return {"kernel": "fused_ir_kernel (features[1..7], expand + depthwise + project per launch)", "bound": "hbm",
+    return {"kernel": "fused inverted-residual launches (fused_ir_kernel: features[1..7]; fused_mid_kernel: features[8..13] where the launch is "
+                      "about one round of the chip): expand + depthwise + project per launch", "bound": "hbm",
             "achieved": round(byts / ms / 1e6, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
             "frac": round(byts / ms / 1e6 / PEAK_HBM_GBS, 4), "traffic": None,
             "launches_per_step": sum(g["launches"] for g in fu.values()), "fused_floor_mb_per_step": round(byts / 1e6, 3),
             "kernel_ms_per_step": round(ms, 4), "tflops_fp32": round(fl / ms / 1e9, 2),
+            "instances": {k: {"launches": g["launches"], "ms": round(g["ms"], 4), "fused_floor_mb": round(g["bytes"] / 1e6, 3),
+                              "frac_hbm": round(g["bytes"] / g["ms"] / 1e6 / PEAK_HBM_GBS, 4), "tflops_fp32": round(g["flops"] / g["ms"] / 1e9, 2)}
+                          for k, g in sorted(fu.items(), key=lambda kv: -kv[1]["ms"])},
             "note": "unfused, the same seven blocks move %.0f MB per step" % (sum(g.get("unfused_bytes", 0.0) for g in fu.values()) / 1e6)}
 
 

@@ -16,7 +16,7 @@ run_set() {   # $1 = prec, $2 = clips, $3 = label, $4 = file tag (bench.py _wl_t
   python3 tools/traffic_report.py $O/f_$T/f_counter_collection.csv $O/w_$T/w_counter_collection.csv $O/r4_hbm_traffic_$T.json "$L" > $O/r4_hbm_traffic_$T.txt
   python3 tools/kernel_stats_report.py $O/kt_$T/kt_kernel_stats.csv $O/r4_kernel_stats_$T.json "$L" > $O/r4_kernel_stats_$T.txt
   cp $O/kt_$T/kt_kernel_stats.csv $O/r4_bench_${T}_kernel_stats.csv
-  python3 tools/step_timeline.py $O/kt_$T/kt_kernel_trace.csv > $O/r4_step_timeline_$T.txt 2>/dev/null || true
+  python3 tools/step_timeline.py $O/kt_$T/kt_kernel_trace.csv 3 --list > $O/r4_step_timeline_$T.txt 2>/dev/null || true
   cp $O/r4_hbm_traffic_$T.json $O/r4_kernel_stats_$T.json profiles/     # so that the bench line below can quote them
   rm -rf $O/f_$T $O/w_$T $O/kt_$T/kt_kernel_trace.csv
 }
