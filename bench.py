@@ -181,7 +181,7 @@ def kernel_rooflines(eng, prec, iters=5):
         if m["kind"].startswith("conv"):
             key = kernel_symbol(prec, m["tile"], 9 if m["kind"] == "conv3" else 1, m.get("streamk", 0), m.get("split", False))
             if m.get("dwproj"):
-                key = "dwproj_kernel<%d, %s>" % (PREC_ID[prec], {256: "2, 4, 2, 2", 128: "2, 4, 2, 1", 64: "4, 2, 1, 1", 32: "4, 1, 1, 1"}[m["dwproj"]])
+                key = "dwproj_kernel<%d, %s, 0>" % (PREC_ID[prec], {256: "2, 4, 2, 2", 128: "2, 4, 2, 1", 64: "4, 2, 1, 1", 32: "4, 1, 1, 1"}[m["dwproj"]])
             elif m.get("fused_dw"):
                 key = "conv_gemm_kernel<%s, true>" % (H16_INST[m["tile"]] % (PREC_ID[prec], 1))
         elif m["kind"] in ("dw", "fused_ir"):
@@ -239,16 +239,19 @@ def depthwise_family(groups):
     return fam
 
 
-def fused_family(groups):
-    """Fused inverted-residual launches: fused-floor bytes (block input + output [+ residual read]) / time."""
-    fu = {k: g for k, g in groups.items() if g["kind"] == "fused_ir"}
+def fused_family(groups, mid=False):
+    """Fused inverted-residual launches: fused-floor bytes (block input + output [+ residual read]) / time.
+    `mid`: the mid-channel kernel's launches (features[8..13]) instead of the small-channel kernel's (features[1..7]) -- a
+    different regime: weights of 0.2-0.4 MB streamed by every workgroup, bound by the matrix pipe / the CU's LDS-DMA rate,
+    so its `frac` against HBM says little; `tflops_fp32` (halo recompute not counted) is the figure to read."""
+    fu = {k: g for k, g in groups.items() if g["kind"] == "fused_ir" and k.startswith("fused_mid") == mid}
     if not fu:
         return None
     byts = sum(g["bytes"] for g in fu.values())
     ms = sum(g["ms"] for g in fu.values())
     fl = sum(g["flops"] for g in fu.values())
-    return {"kernel": "fused inverted-residual launches (fused_ir_kernel: features[1..7]; fused_mid_kernel: features[8..13] where the launch is "
-                      "about one round of the chip): expand + depthwise + project per launch", "bound": "hbm",
+    return {"kernel": ("fused_mid_kernel (features[8..13] where the launch is about one round of the chip: expand + depthwise + project per launch)"
+                       if mid else "fused_ir_kernel (features[1..7], expand + depthwise + project per launch)"), "bound": "hbm",
             "achieved": round(byts / ms / 1e6, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
             "frac": round(byts / ms / 1e6 / PEAK_HBM_GBS, 4), "traffic": None,
             "launches_per_step": sum(g["launches"] for g in fu.values()), "fused_floor_mb_per_step": round(byts / 1e6, 3),
@@ -263,7 +266,7 @@ def dwproj_family(groups, prec):
     """Depthwise -> projection launches with the LDS halo tile (the dwBlocks of the head / decoder): D never reaches
     HBM.  MFMA-bound (fp32 matrix peak) with the depthwise's FLOPs counted; fused-floor bytes (E read + output)
     beside it."""
-    fu = {k: g for k, g in groups.items() if k.startswith("dwproj_kernel")}
+    fu = {k: g for k, g in groups.items() if k.startswith("dwproj_kernel")}      # (template arguments: precision, tile, producer waves)
     if not fu:
         return None
     byts = sum(g["bytes"] for g in fu.values())
@@ -512,6 +515,11 @@ def main():
             if fus:
                 fus["share_of_kernel_time"] = round(fus["kernel_ms_per_step"] / tot, 3)
                 result["roofline_fused"] = fus
+            fmid = fused_family(groups, mid=True)
+            if fmid:
+                fmid["share_of_kernel_time"] = round(fmid["kernel_ms_per_step"] / tot, 3)
+                fmid["frac_mfma"] = round(fmid["tflops_fp32"] / PEAK_TFLOPS["f32"], 4)
+                result["roofline_fused_mid"] = fmid
             dwp = dwproj_family(groups, args.prec)
             if dwp:
                 dwp["share_of_kernel_time"] = round(dwp["kernel_ms_per_step"] / tot, 3)

@@ -47,6 +47,12 @@ __device__ __forceinline__ f32x4 relu6_4(f32x4 v) {
                    __builtin_amdgcn_fmed3f(v.w, 0.f, 6.f)};
 }
 
+#ifndef UAVSAL_FUSED_STAGE_W
+#define UAVSAL_FUSED_STAGE_W 1      /* 0: every wave loads every chunk's weights from global memory (the round-3 kernel) */
+#endif
+#ifndef UAVSAL_FUSED_STAGE_MAX
+#define UAVSAL_FUSED_STAGE_MAX (78 * 1024)   /* ... only where E + weights fit in this many bytes (two workgroups per CU) */
+#endif
 #ifndef UAVSAL_FUSED_NBUF2_MAX
 #define UAVSAL_FUSED_NBUF2_MAX (78 * 1024)     /* two E buffers (one barrier per chunk) when they fit in this many bytes */
 #endif
@@ -71,7 +77,18 @@ struct FusedCfg : FusedGeom<S, TX, PT> {
     static constexpr int EBUF = EXPAND ? (HC / 4) * PLANE : G::NRT * 16 * SLOTF;   // floats per E buffer
     static constexpr int NCH = HID / HC;
     static constexpr int NBUF = (EXPAND && NCH > 1 && 2 * EBUF * 4 <= UAVSAL_FUSED_NBUF2_MAX) ? 2 : 1;
-    static constexpr size_t SMEM = (size_t)NBUF * EBUF * 4;
+    // Round 4: the block's weights are copied into LDS once per workgroup and every chunk's fragments / per-lane constants are
+    // read from there.  Loaded from global memory per chunk and wave they were 27-40 vector-memory instructions per chunk and
+    // wave -- 166-465 per wave and launch (`SQ_INSTS_VMEM`, profiles/r4_sq_pmc_f32_c1.md) -- and the CU's vector-memory issue
+    // (one address-coalescing pipe for its four SIMDs), not the matrix pipe, set the pace of a chunk.  Layout (floats):
+    // w1 [CIN][HID] | s1 | b1 | wd [9][HID] | sd | bd | w2 [HID][COUT]; staged only where two workgroups still fit a CU.
+    static constexpr int W1_F = EXPAND ? CIN * HID + 2 * HID : 0, WD_F = 11 * HID, W2_F = HID * COUT;
+    static constexpr int WOFF_S1 = CIN * HID, WOFF_B1 = WOFF_S1 + HID, WOFF_WD = W1_F, WOFF_SD = WOFF_WD + 9 * HID, WOFF_BD = WOFF_SD + HID,
+                         WOFF_W2 = WOFF_WD + WD_F;
+    static constexpr size_t E_BYTES = (size_t)NBUF * EBUF * 4;
+    static constexpr bool STAGE_W = EXPAND && UAVSAL_FUSED_STAGE_W && E_BYTES + (size_t)(W1_F + WD_F + W2_F) * 4 <= UAVSAL_FUSED_STAGE_MAX;
+    static constexpr int WBASE = NBUF * EBUF;                   // float offset of the staged weights
+    static constexpr size_t SMEM = E_BYTES + (STAGE_W ? (size_t)(W1_F + WD_F + W2_F) * 4 : 0);
 };
 
 #ifndef UAVSAL_FUSED_PROBE
@@ -175,6 +192,24 @@ __global__ __launch_bounds__(256, 2) void fused_ir_kernel(const FusedK p) {
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) acc_o[pt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // ---- the block's weights -> LDS, once per workgroup (16-byte pieces; every segment is a multiple of 4 floats)
+    constexpr bool STAGE_W = Cfg::STAGE_W;
+    float* const wl = lds + Cfg::WBASE;
+    if (STAGE_W) {
+        auto copy_seg = [&](const float* src, int dst_off, int nfloat) {
+            for (int i = tid * 4; i < nfloat; i += 256 * 4) *reinterpret_cast<f32x4*>(wl + dst_off + i) = *reinterpret_cast<const f32x4*>(src + i);
+        };
+        copy_seg(p.w1, 0, CIN * HID);
+        copy_seg(p.s1, Cfg::WOFF_S1, HID);
+        copy_seg(p.b1, Cfg::WOFF_B1, HID);
+        copy_seg(p.wd, Cfg::WOFF_WD, 9 * HID);
+        copy_seg(p.sd, Cfg::WOFF_SD, HID);
+        copy_seg(p.bd, Cfg::WOFF_BD, HID);
+        copy_seg(p.w2, Cfg::WOFF_W2, HID * COUT);
+        __syncthreads();
+    }
+    const float* const g_w1 = STAGE_W ? nullptr : p.w1;
+
     for (int ch = 0; ch < NCH; ++ch) {
         const int c0 = (UAVSAL_FUSED_PROBE & 8) ? 0 : ch * HC;
         // ---- this chunk's weights, as MFMA A fragments / per-lane constants (global loads, cache-resident) ----
@@ -184,25 +219,31 @@ __global__ __launch_bounds__(256, 2) void fused_ir_kernel(const FusedK p) {
 #pragma unroll
             for (int ct = 0; ct < NCTE; ++ct) {
 #pragma unroll
-                for (int s = 0; s < KE; ++s) w1f[ct][s] = p.w1[(size_t)(lq * KE + s) * HID + c0 + ct * 16 + l15];
-                s1q[ct] = *reinterpret_cast<const f32x4*>(p.s1 + c0 + ct * 16 + 4 * lq);
-                b1q[ct] = *reinterpret_cast<const f32x4*>(p.b1 + c0 + ct * 16 + 4 * lq);
+                for (int s = 0; s < KE; ++s)
+                    w1f[ct][s] = STAGE_W ? wl[(lq * KE + s) * HID + c0 + ct * 16 + l15] : g_w1[(size_t)(lq * KE + s) * HID + c0 + ct * 16 + l15];
+                s1q[ct] = STAGE_W ? *reinterpret_cast<const f32x4*>(wl + Cfg::WOFF_S1 + c0 + ct * 16 + 4 * lq)
+                                  : *reinterpret_cast<const f32x4*>(p.s1 + c0 + ct * 16 + 4 * lq);
+                b1q[ct] = STAGE_W ? *reinterpret_cast<const f32x4*>(wl + Cfg::WOFF_B1 + c0 + ct * 16 + 4 * lq)
+                                  : *reinterpret_cast<const f32x4*>(p.b1 + c0 + ct * 16 + 4 * lq);
             }
         }
         f32x4 wdq[9][CQ], sdq[CQ], bdq[CQ];
 #pragma unroll
         for (int q = 0; q < CQ; ++q) {
 #pragma unroll
-            for (int tp = 0; tp < 9; ++tp) wdq[tp][q] = *reinterpret_cast<const f32x4*>(p.wd + (size_t)tp * HID + c0 + lq * CPL + 4 * q);
-            sdq[q] = *reinterpret_cast<const f32x4*>(p.sd + c0 + lq * CPL + 4 * q);
-            bdq[q] = *reinterpret_cast<const f32x4*>(p.bd + c0 + lq * CPL + 4 * q);
+            for (int tp = 0; tp < 9; ++tp)
+                wdq[tp][q] = STAGE_W ? *reinterpret_cast<const f32x4*>(wl + Cfg::WOFF_WD + tp * HID + c0 + lq * CPL + 4 * q)
+                                     : *reinterpret_cast<const f32x4*>(p.wd + (size_t)tp * HID + c0 + lq * CPL + 4 * q);
+            sdq[q] = STAGE_W ? *reinterpret_cast<const f32x4*>(wl + Cfg::WOFF_SD + c0 + lq * CPL + 4 * q) : *reinterpret_cast<const f32x4*>(p.sd + c0 + lq * CPL + 4 * q);
+            bdq[q] = STAGE_W ? *reinterpret_cast<const f32x4*>(wl + Cfg::WOFF_BD + c0 + lq * CPL + 4 * q) : *reinterpret_cast<const f32x4*>(p.bd + c0 + lq * CPL + 4 * q);
         }
         float w2f[NCT][CPL];
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) {
             const int co = ct * 16 + l15;
 #pragma unroll
-            for (int s = 0; s < CPL; ++s) w2f[ct][s] = co < COUT ? p.w2[(size_t)(c0 + lq * CPL + s) * COUT + co] : 0.f;
+            for (int s = 0; s < CPL; ++s)
+                w2f[ct][s] = co < COUT ? (STAGE_W ? wl[Cfg::WOFF_W2 + (c0 + lq * CPL + s) * COUT + co] : p.w2[(size_t)(c0 + lq * CPL + s) * COUT + co]) : 0.f;
         }
 
         float* eb = lds + (NBUF == 2 ? (ch & 1) * EBUF : 0);

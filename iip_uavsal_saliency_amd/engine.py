@@ -73,7 +73,7 @@ FUSE_DW_MAX_WASTE = float(os.environ.get("UAVSAL_FUSE_DW_MAX_WASTE", "1.15"))
 
 # the mid-channel fused block kernel (csrc/fused_mid.hip): workgroups (4 x 8 output patches) of a launch for which it is taken
 MID_MIN_WGS = int(os.environ.get("UAVSAL_MID_MIN_WGS", "1"))
-MID_MAX_WGS = int(os.environ.get("UAVSAL_MID_MAX_WGS", "512"))
+MID_MAX_WGS = int(os.environ.get("UAVSAL_MID_MAX_WGS", "288"))
 
 
 def _dwproj_patch_waste(h, w):
@@ -726,8 +726,9 @@ class Engine:
             self._add(self.lib.uavsal_plan_add_stem, d, "plan_add_stem")
         tapsrc = {}
         cb = g1 = o1 = None
+        priors_at = int(os.environ.get("UAVSAL_PRIORS_AT", "5"))
         for i in range(1, 18):
-            if i == 5:
+            if i == priors_at:
                 self._mark("backbone.0-4", s0)
                 # ---- gaussian / observed prior nets (model.py:349,352): they depend only on the caller's
                 #      priors and are needed at fucb_layer, so they run on lanes 1 and 2 beside the backbone.
