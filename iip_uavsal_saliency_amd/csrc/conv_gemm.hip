@@ -1278,7 +1278,7 @@ int streamk_plan(const uavsal_conv_desc* d, int tile, int ktiles) {
                               : (t1 ? SkSmall::cap<1>() : SkSmall::cap<9>());
     const int kstages = tile == 4 ? (ktiles + 1) / 2 : ktiles;
     const int G = streamk_grid(nblk, kstages, cus, cap, tile != 1);
-    if (G <= 0 || G >= 16000 || d->sk_ws_bytes < 65536 + (long long)G * bm * bn * 4) return 0;
+    if (G <= 0 || G >= UAVSAL_SK_FLAG_MAX || d->sk_ws_bytes < 65536 + (long long)G * bm * bn * 4) return 0;
     return G;
 }
 
@@ -1515,7 +1515,7 @@ extern "C" int uavsal_conv_gemm(const uavsal_conv_desc* d, uavsal_stream_t strea
             // workspace: 64 KB of flags (one per workgroup + a "wait gave up" word), then the partial tiles
             k.sk_flag = (int*)d->sk_ws;
             k.sk_part = (float*)((char*)d->sk_ws + 65536);
-            k.err = d->err ? d->err : (int*)d->sk_ws + (65536 / 4 - 1);
+            k.err = d->err ? d->err : (int*)d->sk_ws + UAVSAL_SK_ERR_WORD;
             const bool t1 = d->taps == 1;
             if (tile == 1) return t1 ? SkBig::launch<1>(k, G, s) : SkBig::launch<9>(k, G, s);
             if (tile == 3) return t1 ? SkThin::launch<1>(k, G, s) : SkThin::launch<9>(k, G, s);

@@ -1030,7 +1030,7 @@ int launch_k32s(const ConvK& k0, int taps, hipStream_t stream) {
     k.nblk = ((k.M + 63) / 64) * k.tiles_n;
     const int stages = k.Kpad / 32;
     int ksp = 1;
-    if (k.kpart && k.sk_flag && (k.epi == UAVSAL_EPI_AFFINE || k.epi == UAVSAL_EPI_TWA) && k.nblk < 16000) {
+    if (k.kpart && k.sk_flag && (k.epi == UAVSAL_EPI_AFFINE || k.epi == UAVSAL_EPI_TWA) && k.nblk < UAVSAL_SK_FLAG_MAX) {
         ksp = (int)(1024 / (k.nblk > 0 ? k.nblk : 1));
         if (ksp > 4) ksp = 4;
         while (ksp > 1 && stages / ksp < 4) --ksp;
