@@ -189,7 +189,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.uavsal_abi_version() != 15:
+    if lib.uavsal_abi_version() != 16:
         raise RuntimeError("libuavsal_hip.so ABI version mismatch")
     for i, t in enumerate(DESC_TYPES):
         if lib.uavsal_sizeof_desc(i) != C.sizeof(t):

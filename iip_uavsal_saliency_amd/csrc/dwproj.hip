@@ -2,6 +2,13 @@
 // the kernel can be rebuilt and probed on its own).
 #include "conv_gemm_common.h"
 
+#ifndef UAVSAL_DWPROJ_TEPI
+#define UAVSAL_DWPROJ_TEPI 0      /* 1: transposed accumulators + 16-byte stores straight from registers instead of the staged epilogue
+                                     (32-row blocks through LDS, eight barriers per tile).  Built in round 4, parity-green, NOT the default:
+                                     a wave store then covers 32 pixels x 32 bytes instead of whole rows -- fp32 one clip 4.390-4.400 vs
+                                     4.385-4.395 ms (st.sp 230 -> 228 us, fucb 68 -> 72), f16x3 eight clips 18.56 vs 18.08 ms */
+#endif
+
 namespace {
 
 // =====================================================================================
@@ -48,6 +55,7 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + PWV) * 64, PWV ? 3 : 1) void d
     constexpr int BM = PH * PW, BN = WAVES_N * WN * 32;
     constexpr int NW = WAVES_M * WAVES_N, NT = (NW + PWV) * 64;      // NW: MFMA waves; NT: all threads of the workgroup
     constexpr int KT = 16, DIST = 4;
+    constexpr bool TEPI = UAVSAL_DWPROJ_TEPI != 0;
     static_assert(PWV == 0 || (PWV == 4 && NW == 8), "producer waves: 8 MFMA waves + 4");
     constexpr int E_REQ = (NHSLOT + 15) / 16;         // 12 wave requests of 16 halo slots, then one for the dw weights
     constexpr int W_OFF = E_REQ * 1024;               // [9 taps | scale | bias][16 channels] behind the halo
@@ -249,11 +257,17 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + PWV) * 64, PWV ? 3 : 1) void d
                     if (H16) {
                         const f16x8 ah = __builtin_bit_cast(f16x8, af[0][i]), al = __builtin_bit_cast(f16x8, af[1][i]);
                         const f16x8 bh = __builtin_bit_cast(f16x8, bfr[0][j]), bl = __builtin_bit_cast(f16x8, bfr[1][j]);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[i][j], 0, 0, 0);
+                        if (TEPI) {      // transposed: rows = output channels, columns = pixels (same products, same order)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, al, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, ah, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah, acc[i][j], 0, 0, 0);
+                        } else {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[i][j], 0, 0, 0);
+                        }
                     } else {
-                        const f32x4 av = af[u][i], bv = bfr[u][j];
+                        const f32x4 av = TEPI ? bfr[u][j] : af[u][i], bv = TEPI ? af[u][i] : bfr[u][j];
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[i][j], 0, 0, 0);
@@ -352,8 +366,56 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + PWV) * 64, PWV ? 3 : 1) void d
             issue_all(0, 0);                       // E slots 0, 1 / weight panels 0, 1; the staging below uses panels 2, 3
             if (nst > 1) issue_all(E_SLOT, B_SLOT);
         }
-        // ---- epilogue: BN, activation, residual; 32-row blocks of the A-tile order through LDS
-        {
+        // ---- epilogue.  TEPI (opt-in, see the macro): the MFMA operands are swapped, so the accumulator lane holds 4 x 4
+        // CONSECUTIVE OUTPUT CHANNELS of one pixel (rows = channels (g & 3) + 8 (g >> 2) + 4 lh, column = pixel lr): BN /
+        // activation / residual and 16-byte stores straight from registers -- no LDS staging, no barriers.
+        if (TEPI) {
+            if (MMA) {
+                const bool part = p.ksplit > 1;
+                const bool vec = !(p.ldc & 3) && !(p.Cout & 3) && !((size_t)p.out & 15) &&
+                                 (!p.res || (!(p.ldr & 3) && !((size_t)p.res & 15)));
+                const int act = part ? UAVSAL_ACT_NONE : p.act;
+#pragma unroll
+                for (int i = 0; i < WM; ++i) {
+                    const int rho = (wm * WM + i) * 32 + lr;            // A-tile row -> pixel (header comment)
+                    const int y = cy0 + 4 * ((rho >> 5) & 1) + ((rho >> 1) & 3);
+                    const int x = cx0 + 8 * (rho >> 6) + 2 * ((rho & 1) + 2 * ((rho >> 4) & 1)) + ((rho >> 3) & 1);
+                    const bool okp = y < p.H && x < p.W;
+                    const long long pix = (long long)y * p.W + x;
+#pragma unroll
+                    for (int j = 0; j < WN; ++j)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int gn = cn0 + (wn * WN + j) * 32 + 4 * lh + 8 * q;
+                            f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                            if (part) {
+                                if (okp && gn < p.Npad)
+                                    *reinterpret_cast<f32x4*>(p.kpart + ((size_t)cks * p.M + (size_t)cimg * p.HW + (size_t)pix) * p.Npad + gn) = v;
+                                continue;
+                            }
+                            if (!okp || gn >= p.Cout) continue;
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                const bool okn = p.scale != nullptr && gn + c < p.Cout;
+                                const float sc = (okn ? p.scale[gn + c] : 1.f) * (H16 ? F16X3_ACC_SCALE : 1.f);
+                                v[c] = apply_act(fmaf(v[c], sc, okn ? p.bias[gn + c] : 0.f), act);
+                            }
+                            float* o = p.out + ((long long)cimg * p.o_is + pix) * p.ldc + gn;
+                            const float* rs = p.res ? p.res + ((long long)cimg * p.r_is + pix) * p.ldr + gn : nullptr;
+                            if (vec) {
+                                if (rs) v += *reinterpret_cast<const f32x4*>(rs);
+                                *reinterpret_cast<f32x4*>(o) = v;
+                                if (H16 && p.out_sp)     // split shadow for the GEMM that consumes this output
+                                    uavsal_store_split4(p.out_sp + ((long long)cimg * p.o_is + pix) * p.ldos, gn, v);
+                            } else {
+#pragma unroll
+                                for (int c = 0; c < 4; ++c)
+                                    if (gn + c < p.Cout) o[c] = v[c] + (rs ? rs[c] : 0.f);
+                            }
+                        }
+                }
+            }
+        } else {
             float* stg = reinterpret_cast<float*>(Bs + 2 * B_SLOT);
             const bool part = p.ksplit > 1;        // K split: raw partial sums out, dwproj_reduce_kernel does the rest
             const bool vec = !(p.ldc & 3) && !(p.Cout & 3) && !((size_t)p.out & 15) &&

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define UAVSAL_ABI_VERSION 15
+#define UAVSAL_ABI_VERSION 16
 
 /* argument errors */
 #define UAVSAL_EINVAL   (-1)  /* null pointer / non-positive size */
