@@ -580,7 +580,7 @@ def main():
                 # the depthwise family (north_star: >= 60 % of the HBM roofline) on THIS leg too: at one clip its launches sit on
                 # the per-launch floor, at eight clips per GPU (what every GPU of configs[3] runs) they are bandwidth-bound
                 eng8 = model._engine(device, 8, T, H, W, "clip", False, torch.float32)
-                g8 = kernel_rooflines(eng8, args.prec, iters=3)
+                g8 = kernel_rooflines(eng8, args.prec, iters=5)
                 fam8 = depthwise_family(g8)
                 if fam8:
                     fam8["workload"] = result["scaling_reference"]["workload"]
