@@ -14,6 +14,7 @@
 //   * blockIdx is remapped so each XCD works on a contiguous slab of (image, row-band)
 //     work: the halo rows shared by neighbouring patches are served by the same L2.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -207,8 +208,13 @@ int launch_map_lds(DwK k, hipStream_t s) {
 static inline int map_lds_slab(const DwK& k) {
     const long long px = (long long)k.H * k.W;
     if (px * 16 * 4 > 65536) return 0;
-    const int cands[3] = {64, 32, 16};
-    for (int i = 0; i < 3; ++i) {      // widest slab that fits and still gives every CU a workgroup
+    static const int forced = [] { const char* e = getenv("UAVSAL_DW_MAP_CB"); return e ? atoi(e) : 0; }();
+    if ((forced == 16 || forced == 32 || forced == 64) && px * forced * 4 <= 65536) return forced;
+    // 32 channels (30 KB of LDS at 12x20: five workgroups per CU cover each other's load / compute phases) where that still
+    // gives every CU a workgroup, else 16.  (64-channel slabs, two workgroups per CU: 78.7 vs 51.9 us at 64 x 12x20 x 1920
+    // and 15.1 vs 11.0 us at 8 frames -- round 4)
+    const int cands[2] = {32, 16};
+    for (int i = 0; i < 2; ++i) {
         const int cb = cands[i];
         if (px * cb * 4 <= 65536 && (long long)k.n_img * ((k.C4 * 4 + cb - 1) / cb) >= 256) return cb;
     }
