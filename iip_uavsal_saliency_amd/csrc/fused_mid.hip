@@ -8,15 +8,23 @@
 // GEMM-shaped form of the same fusion:
 //   * one 256-thread workgroup owns a 4 x 8 patch of output pixels (23x40 x 8 frames: 240 workgroups, one per CU);
 //   * x of the 6 x 10 halo (64 rows, 4 of them padding) is staged ONCE in LDS by LDS-DMA and its MFMA fragments are kept in
-//     registers for every hidden chunk;
+//     registers for every hidden chunk (the depthwise output D later reuses that LDS space);
 //   * the hidden channels are walked 64 at a time; the chunk's weights -- W1[64 hidden][Cin], W2[Cout][64 hidden], both in
-//     the conv weight's natural layout, and the depthwise taps -- arrive by LDS-DMA one chunk ahead (two buffers);
+//     the conv weight's natural layout -- and its parameter vectors (9 taps + BN2, BN1) arrive by LDS-DMA a chunk ahead, two
+//     buffers each, from running per-lane source pointers; every wave issues the same 9-13 requests per chunk, one per slice
+//     of the iteration (below);
 //   * expand:  E^T[hidden][pixel] = W1c . x^T on v_mfma_f32_32x32x2_f32 (exact fp32), four 32 x 32 tiles = one per wave;
 //     the accumulator lane holds 4 x 4 consecutive hidden channels of one pixel: relu6(bn1), EXACT ZERO outside the image
 //     (the depthwise conv pads E, not x), four ds_write_b128 into E[pixel][64];
-//   * depthwise: a thread owns (two pixels, 4 channels): 18 + 9 ds_read_b128, relu6(bn2) -> D[pixel][64];
+//   * depthwise: a thread owns (a pair of horizontally adjacent pixels, 4 channels): its 3 x 4 halo pixels are read once for
+//     both (12 ds_read_b128), taps / BN2 from LDS, relu6(bn2) -> D[pixel][64];
 //   * project: OUT^T[cout][pixel] += W2c . D^T, every wave takes a quarter of the chunk's K for all Cout tiles; the four
-//     partial accumulators are summed once at the end through LDS in wave order (deterministic), then bn3 / residual / store.
+//     partial accumulators are summed once at the end through LDS in wave order (deterministic), then bn3 / residual / store;
+//   * ONE barrier per chunk: iteration c runs expand(c + 1), depthwise(c) and project(c - 1) (E and D double-buffered), and
+//     because a one-wave-per-SIMD kernel gets no overlap from the hardware, the iteration is hand-cut into slices
+//     [first MFMA of a group][one halo pixel's FMAs] | [the slice's LDS-DMA request] | [LDS reads of the NEXT slice] |
+//     [the group's other three MFMAs], pinned with sched_barrier / asm volatile.  profiles/r4_fused_mid.md has the versions,
+//     the in-kernel stamps and what bounds it now (the weight stream: 35 KB per chunk and workgroup by LDS-DMA).
 // LDS rows are 256 B (or 384 B) with the 16-byte chunk index XOR-swizzled by the row (conflict-free ds_read_b128 fragment
 // reads); the swizzle is applied on the SOURCE address of the DMA requests (their LDS image is lane-linear).
 // MFMA lane maps (cdna_hip_programming.md; the same as conv_gemm_k32.hip): A[m = l & 31][k from l >> 5], B[k][n = l & 31],
