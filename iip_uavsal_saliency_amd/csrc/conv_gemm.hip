@@ -1355,7 +1355,9 @@ static int effective_tile(const uavsal_conv_desc* d) {
         static const int small_mode = [] { const char* e = getenv("UAVSAL_K32_SMALL"); return e ? atoi(e) : 1; }();
         const long long M = (long long)d->H * d->W * d->n_img;
         const long long tiles64 = ((M + 63) / 64) * ((d->Cout + 63) / 64);
-        if (k32_mode && small_mode && tiles64 <= 160 && d->taps * d->Cin / 32 >= 24 && uavsal_f32_k32_eligible(d, 11) &&
+        // (round 4: from 12 stages on -- features.14's projection, K = 576: 16.9 -> 13.9 us; the context prior's, K = 384 on one
+        // 12x20 map: 12.9 -> 10.0)
+        if (k32_mode && small_mode && tiles64 <= 160 && d->taps * d->Cin / 32 >= 12 && uavsal_f32_k32_eligible(d, 11) &&
             d->act != UAVSAL_ACT_SIGMOID && !(d->Cout & 3) && !(d->ldc & 3))
             tile = 11;
     }
@@ -1366,7 +1368,8 @@ static int effective_tile(const uavsal_conv_desc* d) {
         static const int exp_mode = [] { const char* e = getenv("UAVSAL_K32_SMALL_EXPAND"); return e ? atoi(e) : 1; }();
         const long long M = (long long)d->H * d->W * d->n_img;
         const long long tiles64 = ((M + 63) / 64) * ((d->Cout + 63) / 64);
-        if (k32_mode && exp_mode && M <= 8192 && tiles64 <= 768 && d->Cout >= 256 && d->Cin >= 64 && d->Cin <= 192 &&
+        // (round 4: up to Cin = 256 and two rounds of tiles -- the context prior's expand, 256 -> 1536 on ONE 45x80 map: 40.4 -> 34.2 us)
+        if (k32_mode && exp_mode && M <= 8192 && tiles64 <= 1536 && d->Cout >= 256 && d->Cin >= 64 && d->Cin <= 256 &&
             !d->w_group_stride && !d->n_group && uavsal_f32_k32_eligible(d, 11) && d->act != UAVSAL_ACT_SIGMOID && !(d->Cout & 3) && !(d->ldc & 3))
             tile = 11;
     }

@@ -76,6 +76,9 @@ MID_MIN_WGS = int(os.environ.get("UAVSAL_MID_MIN_WGS", "1"))
 MID_MAX_WGS = int(os.environ.get("UAVSAL_MID_MAX_WGS", "288"))
 
 
+_TILE_OVERRIDE = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in os.environ.get("UAVSAL_TILE_OVERRIDE", "").split(",") if "=" in kv}
+
+
 def _dwproj_patch_waste(h, w):
     return ((h + 7) // 8 * 8) * ((w + 15) // 16 * 16) / float(h * w)
 
@@ -423,6 +426,8 @@ class Engine:
         side_tile = int(os.environ.get("UAVSAL_SIDE_TILE", "11"))      # (5.155 vs 5.17 ms per step, same box, two runs each)
         if side_tile and self._lane != 0 and pn == "f32" and epi == L.EPI_AFFINE and dw is None and cin % 32 == 0:
             d.tile = side_tile
+        if name in _TILE_OVERRIDE:           # experiments: UAVSAL_TILE_OVERRIDE="ctx.0.pw=11,ctx.1.pl=11"
+            d.tile = _TILE_OVERRIDE[name]
         if out2 is not None:
             d.out2, d.ld2 = out2.ptr, out2.ld
         if self.stream_k:

@@ -181,7 +181,7 @@ def test_default_fp32_plan_composition(hip_model):
     pinned: no stream-K launch is left, the dense 3x3 convs are Winograd triples, the three dilated ASPP projections are one
     grouped launch, the 384-hidden blocks at 45x80 run depthwise + projection fused, features[1..7] are one launch each, and
     the small-map blocks (patch grid > 15 % outside the map) keep separate depthwise / projection launches."""
-    hip_model.precision = "f32"
+    hip_model.precision, hip_model.time_dims = "f32", 8          # (whatever an earlier test left on the shared model)
     eng = hip_model._engine(torch.device("cuda", torch.cuda.current_device()), 1, 8, 360, 640, "tile")
     meta = {m["name"]: m for m in eng.ops_meta}
     assert all(m.get("streamk", 0) == 0 for m in eng.ops_meta)
