@@ -1385,6 +1385,15 @@ static int effective_tile(const uavsal_conv_desc* d) {
             tile = (k32_mode == 9 && d->Cout % 128 == 0 && ((M + 255) / 256) * (d->Cout / 128) >= 1024) ? 9 : 8;
         }
     }
+    // ... and a 1x1 whose 128 x 128 tiles are more than one per CU but fewer than the 512 resident slots (the STBlock's
+    // 256 -> 256 output conv at one clip: 450 tiles, so most CUs run two and the rest one) takes the 64 x 64 instance: 49.6 -> 46.7 us
+    if (d->tile == 0 && tile == 8 && d->prec == UAVSAL_PREC_F32 && d->epi == UAVSAL_EPI_AFFINE && d->taps == 1 && !d->w_group_stride) {
+        const long long M = (long long)d->H * d->W * d->n_img;
+        const long long tiles128 = ((M + 127) / 128) * ((d->Cout + 127) / 128);
+        if (tiles128 > 256 && tiles128 < 512 && d->Cin >= 128 && d->Cout <= 256 && uavsal_f32_k32_eligible(d, 11) &&
+            d->act != UAVSAL_ACT_SIGMOID && !(d->Cout & 3) && !(d->ldc & 3))
+            tile = 11;
+    }
     if (tile == 7 && (d->prec != UAVSAL_PREC_F32 || d->dw_w9c)) tile = 1;     // 256 x 128 exists for the fp32 LDS-DMA kernel
     if (tile == 6) {   // the 256 x 256 tile only carries the vector epilogue
         const bool vec = d->epi == UAVSAL_EPI_AFFINE && d->act != UAVSAL_ACT_SIGMOID && !(d->ldc & 3) &&
