@@ -294,7 +294,7 @@ def timed_steps(fn, steps, warmup, distributed, device):
         dist.barrier()
     dt = time.perf_counter() - t0
     if distributed:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt
@@ -317,6 +317,8 @@ def self_launch(n, argv, worker=None, poll_s=0.2):
     import socket
     import subprocess
     have = visible_gpus()
+    if "--rehearse-on-one-gpu" in argv:
+        have = n if have >= 1 else 0           # every rank uses cuda:0 (see --rehearse-on-one-gpu)
     if have < n:
         print("bench.py: --gpus %d asked for but only %d GPU(s) visible; not measuring a smaller job" % (n, have),
               file=sys.stderr, flush=True)
@@ -385,6 +387,9 @@ def main():
     ap.add_argument("--persistent-state", type=int, default=0, help="1: BASELINE configs[4]'s mode -- the recurrent state stays in the "
                     "engine's HBM buffer between steps (model.persistent_state) and every step continues from the previous one's state; "
                     "0: every step gets a caller-owned state tensor (staged NCHW -> NHWC, returned as a fresh NCHW tensor)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true", help="with --gpus N: the N ranks all use cuda:0 and rendezvous over gloo "
+                    "(maps gathered through the host).  NOT a measurement of anything -- it runs the launcher, the rank environment, the "
+                    "clip partition, the gather and the barrier-bracketed timing with the HIP engine on a one-GPU box; the line says so")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
@@ -405,11 +410,15 @@ def main():
                          % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU path to measure")
-    device = torch.device("cuda", local_rank)
+    rehearsal = bool(args.rehearse_on_one_gpu) and distributed
+    device = torch.device("cuda", 0 if rehearsal else local_rank)
     torch.cuda.set_device(device)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from iip_uavsal_saliency_amd import UAVSal, synth
     from iip_uavsal_saliency_amd.parallel import ClipShard, gather_maps
@@ -469,6 +478,11 @@ def main():
     }
 
     result["ranks_seen"] = dist.get_world_size() if distributed else 1
+    if rehearsal:
+        result["n_gpus"] = 1
+        result["rehearsal"] = ("%d ranks SHARING one GPU over gloo (maps gathered through the host): exercises launcher, rank env, clip "
+                               "partition, gather and timing protocol only; value is NOT a multi-GPU figure" % world)
+        result["config"]["parallelism"] = "REHEARSAL: %d ranks on one GPU, gloo" % world
     result["peak_device_memory_mb"] = round(torch.cuda.max_memory_allocated(device) / 1e6, 1)      # weights + plan buffers + inputs
     if distributed and not args.no_extra:
         # the like-for-like origin of the weak-scaling curve, in the line itself: the SAME per-GPU workload on rank 0's GPU

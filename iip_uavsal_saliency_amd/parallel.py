@@ -54,7 +54,12 @@ def gather_maps(local_out: torch.Tensor, gathered: Optional[torch.Tensor] = None
         gathered = torch.empty((local_out.shape[0] * world,) + tuple(local_out.shape[1:]),
                                dtype=local_out.dtype, device=local_out.device)
     if dist.get_backend() == "gloo":
-        dist.all_gather(list(gathered.chunk(world, 0)), local_out)
+        if local_out.is_cuda:       # gloo has no device all-gather: through the host (one-GPU rehearsals of the rank protocol only)
+            parts = [torch.empty(local_out.shape, dtype=local_out.dtype) for _ in range(world)]
+            dist.all_gather(parts, local_out.cpu())
+            gathered.copy_(torch.cat(parts))
+        else:
+            dist.all_gather(list(gathered.chunk(world, 0)), local_out)
     else:
         dist.all_gather_into_tensor(gathered, local_out)
     return gathered

@@ -31,10 +31,14 @@ rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 C = int(os.environ["UAVSAL_C"])
 T, H, W = (int(v) for v in os.environ.get("UAVSAL_THW", "3,72,104").split(","))
 h, w = H // 8, W // 8
-dev = torch.device("cuda", rank)
+share = os.environ.get("UAVSAL_SHARE_GPU") == "1"          # rehearsal on a one-GPU box: every rank on cuda:0, gloo
+dev = torch.device("cuda", 0 if share else rank)
 torch.cuda.set_device(dev)
-dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-assert dist.get_backend() == "nccl" and dist.get_world_size() == world
+if share:
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+else:
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+assert dist.get_backend() == ("gloo" if share else "nccl") and dist.get_world_size() == world
 def clips(first, count):
     xs, g, o = [], [], []
     for c in range(first, first + count):
@@ -79,9 +83,10 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run_ranks(world, clips, thw):
+def _run_ranks(world, clips, thw, share_gpu=False):
     env = dict(os.environ, UAVSAL_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
-               WORLD_SIZE=str(world), UAVSAL_C=str(clips), UAVSAL_THW=thw, HSA_ENABLE_IPC_MODE_LEGACY="0")
+               WORLD_SIZE=str(world), UAVSAL_C=str(clips), UAVSAL_THW=thw, HSA_ENABLE_IPC_MODE_LEGACY="0",
+               UAVSAL_SHARE_GPU="1" if share_gpu else "0")
     procs = []
     for r in range(world):
         procs.append(subprocess.Popen([sys.executable, "-c", WORKER], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
@@ -117,6 +122,34 @@ def test_sharded_benchmark_shape_two_ranks():
     if n < 2:
         pytest.skip("needs 2 GPUs, %d visible" % n)
     _run_ranks(2, 16, "8,360,640")
+
+
+def test_two_ranks_sharing_one_gpu_rehearsal():
+    """What a one-GPU box CAN execute of the N-rank path: two rank processes, both on cuda:0, rendezvous over gloo, each
+    running the HIP model on its own clips through `forward_clips_sharded`, maps gathered through the host.  Same checks
+    as the RCCL test (bit-identical to the shards run one after another, carried local states, 5e-4 against the whole batch
+    in one call).  The RCCL all-gather itself is the one call this does not reach."""
+    if torch.cuda.device_count() < 1:
+        pytest.skip("needs a GPU")
+    _run_ranks(2, 4, "3,72,104", share_gpu=True)
+
+
+def test_bench_two_rank_rehearsal_on_one_gpu():
+    """`bench.py --gpus 2 --rehearse-on-one-gpu`: the self-launcher, the rank environment, the clip partition, the gather and
+    the barrier-bracketed max-over-ranks timing with the HIP engine under them; the line must say it is a rehearsal."""
+    import json
+    if torch.cuda.device_count() < 1:
+        pytest.skip("needs a GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--clips", "1",
+                        "--steps", "3", "--warmup", "1", "--windows", "1", "--no-extra", "--no-cpu-baseline", "--no-roofline"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["ranks_seen"] == 2 and r["n_gpus"] == 1 and "rehearsal" in r and r["value"] > 0
+    assert r["config"]["clips_per_gpu"] == 1 and r["steps"] == 3
 
 
 DEVICE_WORKER = r'''
