@@ -1278,7 +1278,7 @@ int streamk_plan(const uavsal_conv_desc* d, int tile, int ktiles) {
                               : (t1 ? SkSmall::cap<1>() : SkSmall::cap<9>());
     const int kstages = tile == 4 ? (ktiles + 1) / 2 : ktiles;
     const int G = streamk_grid(nblk, kstages, cus, cap, tile != 1);
-    if (G <= 0 || G >= UAVSAL_SK_FLAG_MAX || d->sk_ws_bytes < 65536 + (long long)G * bm * bn * 4) return 0;
+    if (G <= 0 || G >= UAVSAL_SK_STREAMK_MAX || d->sk_ws_bytes < 65536 + (long long)G * bm * bn * 4) return 0;
     return G;
 }
 
@@ -1535,7 +1535,7 @@ extern "C" int uavsal_conv_gemm(const uavsal_conv_desc* d, uavsal_stream_t strea
         }
     }
     if (tile >= 8 && tile <= 11) {
-        if (k.kpart) k.sk_flag = (int*)d->sk_ws;       // per-tile arrival counters of the K-split launch (zero between launches)
+        if (k.kpart) k.sk_flag = (int*)d->sk_ws + UAVSAL_SK_TICKET_BASE;       // per-tile ticket counters of the K-split launch: their own region
         return uavsal_launch_f32_k32(k, d->taps, tile, s);
     }
     switch (d->prec) {

@@ -299,15 +299,20 @@ int launch_splitk_reduce(const ConvK& k, float acc_scale, hipStream_t stream) {
     return uavsal_launch_status();
 }
 
-// The first 64 KB of a conv's workspace (uavsal_conv_desc.sk_ws) are 16384 words of flags: stream-K "published" flags, the
-// per-tile ticket counters of the in-launch K-share reduction (tiles 10 / 11), and -- when the descriptor carries no error
-// word of its own -- the fallback error word in the LAST one.  Flag / ticket indices must stay below it: every user
-// bounds its grid / tile count with UAVSAL_SK_FLAG_MAX.  (Both users leave the block zero when a launch ends; after a
-// stream-K time-out the host re-zeroes it before the next launch: Engine.check.)
+// The first 64 KB of a conv's workspace (uavsal_conv_desc.sk_ws) are 16384 words in three regions that never overlap:
+//   [0, UAVSAL_SK_TICKET_BASE)                  stream-K "published" flags, one per workgroup of the launch (G < UAVSAL_SK_STREAMK_MAX)
+//   [UAVSAL_SK_TICKET_BASE, UAVSAL_SK_ERR_WORD) per-tile ticket counters of the in-launch K-share reduction (tiles 10 / 11;
+//                                               tile count < UAVSAL_SK_TICKET_MAX)
+//   UAVSAL_SK_ERR_WORD                          the fallback error word, when the descriptor carries none of its own
+// Both users leave their region zero when a launch ends.  A stream-K wait that gave up leaves flags behind in the FIRST region
+// only (the host re-zeroes the block before the next forward: Engine.check): the ticket counters of later launches of the
+// same run are not touched by it.
 #define UAVSAL_SK_FLAG_WORDS (65536 / 4)
 #define UAVSAL_SK_ERR_WORD (UAVSAL_SK_FLAG_WORDS - 1)
-#define UAVSAL_SK_FLAG_MAX 16000
-static_assert(UAVSAL_SK_FLAG_MAX < UAVSAL_SK_ERR_WORD, "flag / ticket indices stay below the fallback error word");
+#define UAVSAL_SK_TICKET_BASE 4096
+#define UAVSAL_SK_STREAMK_MAX UAVSAL_SK_TICKET_BASE
+#define UAVSAL_SK_TICKET_MAX (UAVSAL_SK_ERR_WORD - UAVSAL_SK_TICKET_BASE)
+static_assert(UAVSAL_SK_TICKET_BASE + UAVSAL_SK_TICKET_MAX <= UAVSAL_SK_ERR_WORD, "ticket indices stay below the fallback error word");
 #define UAVSAL_SPLIT_REF_SLOTS 512          /* dwproj_kernel's narrow instance: two workgroups per CU */
 #define UAVSAL_SPLIT_REF_SLOTS_64 1024      /* the register-staged 64 x 64 tiles (32 KB of LDS): four per CU */
 

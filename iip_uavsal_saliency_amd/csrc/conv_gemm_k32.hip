@@ -900,14 +900,20 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_f32_k32s_kernel(const ConvK 
     }
 }
 
-// may this launch split K (workspace there and large enough for 8 shares, epilogue the reduce step carries, vector
-// alignment)?  -- the number of shares itself is uavsal_f32_k32_ksplit(tiles, stages)
-bool uavsal_f32_k32_split_ok(const ConvK& k) {
+// may this launch split K?  (a) the gates every in-launch reduction needs: ticket region and partial area there, an epilogue
+// the reducing share carries, vector alignment, tile count inside the ticket region; (b) partial area large enough for 8 shares
+// of the unpadded output (the 128 x 128 kernels; the 64 x 64 kernel sizes its own <= 4 whole-tile shares).
+// The number of shares itself is uavsal_f32_k32_ksplit(tiles, stages).
+bool uavsal_f32_k32_split_gates(const ConvK& k) {
     if (!k.kpart || !k.sk_flag || (k.epi != UAVSAL_EPI_AFFINE && k.epi != UAVSAL_EPI_TWA) || k.act == UAVSAL_ACT_SIGMOID) return false;
-    if (8LL * k.M * k.Npad * 4 > k.kpart_bytes || (k.Cout & 3) || (k.ldc & 3) || ((size_t)k.out & 15)) return false;
+    if (k.nblk <= 0 || k.nblk >= UAVSAL_SK_TICKET_MAX) return false;
+    if ((k.Cout & 3) || (k.ldc & 3) || ((size_t)k.out & 15)) return false;
     if (k.res && ((k.ldr & 3) || ((size_t)k.res & 15))) return false;
     if (k.epi == UAVSAL_EPI_TWA && ((k.ldx & 3) || (k.lda & 3) || !k.res || !k.aux || ((size_t)k.aux & 15))) return false;
     return true;
+}
+bool uavsal_f32_k32_split_ok(const ConvK& k) {
+    return uavsal_f32_k32_split_gates(k) && 8LL * k.M * k.Npad * 4 <= k.kpart_bytes;
 }
 
 template <int WAVES_M, int WAVES_N, int MINW, bool FLAT = false>
@@ -1030,7 +1036,7 @@ int launch_k32s(const ConvK& k0, int taps, hipStream_t stream) {
     k.nblk = ((k.M + 63) / 64) * k.tiles_n;
     const int stages = k.Kpad / 32;
     int ksp = 1;
-    if (k.kpart && k.sk_flag && (k.epi == UAVSAL_EPI_AFFINE || k.epi == UAVSAL_EPI_TWA) && k.nblk < UAVSAL_SK_FLAG_MAX) {
+    if (uavsal_f32_k32_split_gates(k)) {
         ksp = (int)(1024 / (k.nblk > 0 ? k.nblk : 1));
         if (ksp > 4) ksp = 4;
         while (ksp > 1 && stages / ksp < 4) --ksp;
