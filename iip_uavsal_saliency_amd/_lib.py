@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("UAVSAL_HIP_LIB") or os.path.join(PKG, "libuavsal_hip.
 PREC = {"f32": 0, "bf16x3": 1, "bf16": 2, "f16x3": 3}
 ACT_NONE, ACT_RELU6, ACT_SIGMOID = 0, 1, 2
 EPI_AFFINE, EPI_TWA, EPI_LSTM = 0, 1, 2
+SK_TICKET_BASE = 4096      # words of stream-K flags in front of the K-split ticket counters (csrc/conv_gemm_common.h)
 
 _ERR = {-1: "UAVSAL_EINVAL (null pointer / non-positive size)",
         -2: "UAVSAL_EALIGN (channel count / ld / pointer not 16-byte aligned)",

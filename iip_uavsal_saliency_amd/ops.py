@@ -69,7 +69,7 @@ def _empty_shadow(n, h, w, c, device):
 
 
 def conv_gemm(x, weight, scale=None, bias=None, act=L.ACT_NONE, res=None, out=None, prec="f32", tile=0, dw=None,
-              stream_k=False, sk_spin_limit=0, sk_debug_drop=0, split_in=False, split_out=False, n_group=0):
+              stream_k=False, sk_spin_limit=0, sk_debug_drop=0, split_in=False, split_out=False, n_group=0, _stale_streamk_flags=False):
     """Dense 1x1 / 3x3 conv (+ folded BN, activation, residual).  `weight` [Cout,Cin,k,k] (cpu or cuda).
     `n_group`: several 1x1 convs of different inputs as one launch -- `x` holds the inputs side by side ([.., groups * Cin]),
     `weight` [groups * n_group, Cin, 1, 1] the stacked weights (uavsal_conv_desc.n_group / a_group_off).
@@ -122,6 +122,8 @@ def conv_gemm(x, weight, scale=None, bias=None, act=L.ACT_NONE, res=None, out=No
         keep.append(ws)
         d.sk_ws, d.sk_ws_bytes = ws.data_ptr(), ws.numel()
         d.sk_spin_limit, d.sk_debug_drop = sk_spin_limit, sk_debug_drop
+        if _stale_streamk_flags:        # test hook: what a stream-K wait that gave up earlier on this lane leaves behind
+            ws[:4 * L.SK_TICKET_BASE].view(torch.int32).fill_(1)
     d.w = 1 << 20
     uses_split = int(lib.uavsal_conv_uses_split(C.byref(d))) == 1
     if split_in and not uses_split:
@@ -134,7 +136,7 @@ def conv_gemm(x, weight, scale=None, bias=None, act=L.ACT_NONE, res=None, out=No
     d.w = wp.data_ptr()
     L.check(lib.uavsal_conv_gemm(C.byref(d), _stream(x)), "uavsal_conv_gemm")
     torch.cuda.current_stream(x.device).synchronize()   # `keep` must outlive the launch
-    if stream_k:
+    if stream_k and not _stale_streamk_flags:
         _streamk_outcome(ws, "uavsal_conv_gemm")
     return (out, shadow) if split_out else out
 

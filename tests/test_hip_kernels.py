@@ -324,6 +324,23 @@ def test_conv_f32_full_line_split_k(ops, case):
         assert (nchw(got) - ref).abs().max().item() <= TOL["f32"] * 4.0, (tile, case)
 
 
+@pytest.mark.parametrize("tile", [10, 11])
+def test_k_split_tickets_survive_stale_streamk_flags(ops, tile):
+    """the ticket counters of the in-launch K-share reduction have their own region of the workspace's flag block: flags a
+    stream-K wait that gave up left behind (first region, re-zeroed by the host only before the NEXT forward) must not move a later
+    launch's tickets.  Same result, bit for bit, with a clean and with a dirtied flag region."""
+    n, h, w, cin, cout = 2, 12, 20, 1920, 256
+    x = rnd((n, cin, h, w), 153, 2.0)
+    wt = rnd((cout, cin, 1, 1), 154, 1.0 / np.sqrt(cin))
+    scale = rnd((cout,), 155) * 0.5 + 1.0
+    bias = rnd((cout,), 156)
+    ref = act_ref(F.conv2d(x, wt) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1), 1)
+    clean = ops.conv_gemm(nhwc(x), wt, scale, bias, act=1, prec="f32", tile=tile, stream_k=True)
+    dirty = ops.conv_gemm(nhwc(x), wt, scale, bias, act=1, prec="f32", tile=tile, stream_k=True, _stale_streamk_flags=True)
+    assert torch.equal(clean, dirty), tile
+    assert (nchw(dirty) - ref).abs().max().item() <= TOL["f32"] * 4.0, tile
+
+
 @pytest.mark.parametrize("tile", [8, 9, 10, 11])
 @pytest.mark.parametrize("case", [(2, 12, 20, 256, 1536, 1, 1, False), (1, 23, 40, 1536, 256, 1, 0, True),
                                   (3, 7, 5, 320, 256, 1, 1, False), (1, 45, 80, 32, 256, 1, 1, True),
