@@ -50,11 +50,8 @@ __device__ __forceinline__ f32x4 relu6_4(f32x4 v) {
 #ifndef UAVSAL_FUSED_STAGE_W
 #define UAVSAL_FUSED_STAGE_W 1      /* 0: every wave loads every chunk's weights from global memory (the round-3 kernel) */
 #endif
-#ifndef UAVSAL_FUSED_STAGE_MAX
-#define UAVSAL_FUSED_STAGE_MAX (78 * 1024)   /* ... only where E + weights fit in this many bytes (two workgroups per CU) */
-#endif
 #ifndef UAVSAL_FUSED_NBUF2_MAX
-#define UAVSAL_FUSED_NBUF2_MAX (78 * 1024)     /* two E buffers (one barrier per chunk) when they fit in this many bytes */
+#define UAVSAL_FUSED_NBUF2_MAX (80 * 1024)     /* two E buffers (one barrier per chunk) when they fit, with the staged weights, in this many bytes */
 #endif
 
 template <int S, int TX, int PT>
@@ -76,24 +73,34 @@ struct FusedCfg : FusedGeom<S, TX, PT> {
     static constexpr int SLOTF = EXPAND ? 4 : HC + 4;
     static constexpr int EBUF = EXPAND ? (HC / 4) * PLANE : G::NRT * 16 * SLOTF;   // floats per E buffer
     static constexpr int NCH = HID / HC;
-    static constexpr int NBUF = (EXPAND && NCH > 1 && 2 * EBUF * 4 <= UAVSAL_FUSED_NBUF2_MAX) ? 2 : 1;
-    // Round 4: the block's weights are copied into LDS once per workgroup and every chunk's fragments / per-lane constants are
-    // read from there.  Loaded from global memory per chunk and wave they were 27-40 vector-memory instructions per chunk and
-    // wave -- 166-465 per wave and launch (`SQ_INSTS_VMEM`, profiles/r4_sq_pmc_f32_c1.md) -- and the CU's vector-memory issue
-    // (one address-coalescing pipe for its four SIMDs), not the matrix pipe, set the pace of a chunk.  Layout (floats):
-    // w1 [CIN][HID] | s1 | b1 | wd [9][HID] | sd | bd | w2 [HID][COUT]; staged only where two workgroups still fit a CU.
-    static constexpr int W1_F = EXPAND ? CIN * HID + 2 * HID : 0, WD_F = 11 * HID, W2_F = HID * COUT;
-    static constexpr int WOFF_S1 = CIN * HID, WOFF_B1 = WOFF_S1 + HID, WOFF_WD = W1_F, WOFF_SD = WOFF_WD + 9 * HID, WOFF_BD = WOFF_SD + HID,
-                         WOFF_W2 = WOFF_WD + WD_F;
+    // Round 4: a chunk's weights are staged in LDS (two buffers, filled a chunk ahead: global loads at the top of chunk ch, LDS
+    // writes in front of its barrier) and every fragment / per-lane constant is read from there.  Loaded from global memory per
+    // chunk and wave they were 27-40 vector-memory instructions per chunk and wave -- 166-465 per wave and launch
+    // (`SQ_INSTS_VMEM`, profiles/r4_sq_pmc_f32_c1.md) -- and the CU's vector-memory issue (one address-coalescing pipe for its
+    // four SIMDs), not the matrix pipe, set the pace of a chunk.  (First form, kept until the stamps of tools/fir_stamps.py: the
+    // WHOLE block's weights copied once per workgroup -- 20-82 KB, so only the stride-1 instances could afford it.)
+    // Chunk layout (floats): w1 [CIN][HC] | s1 [HC] | b1 [HC] | wd [9][HC] | sd [HC] | bd [HC] | w2 [HC][COUT].
+    static constexpr int CW_S1 = CIN * HC, CW_B1 = CW_S1 + HC, CW_WD = CW_B1 + HC, CW_SD = CW_WD + 9 * HC, CW_BD = CW_SD + HC,
+                         CW_W2 = CW_BD + HC, CW_F = CW_W2 + HC * COUT;
+    static constexpr bool STAGE_W = EXPAND && UAVSAL_FUSED_STAGE_W;
+    static constexpr int NBUF = (EXPAND && NCH > 1 && (2 * EBUF + (STAGE_W ? 2 * CW_F : 0)) * 4 <= UAVSAL_FUSED_NBUF2_MAX) ? 2 : 1;
     static constexpr size_t E_BYTES = (size_t)NBUF * EBUF * 4;
-    static constexpr bool STAGE_W = EXPAND && UAVSAL_FUSED_STAGE_W && E_BYTES + (size_t)(W1_F + WD_F + W2_F) * 4 <= UAVSAL_FUSED_STAGE_MAX;
     static constexpr int WBASE = NBUF * EBUF;                   // float offset of the staged weights
-    static constexpr size_t SMEM = E_BYTES + (STAGE_W ? (size_t)(W1_F + WD_F + W2_F) * 4 : 0);
+    static constexpr size_t SMEM = E_BYTES + (STAGE_W ? (size_t)2 * CW_F * 4 : 0);
 };
 
 #ifndef UAVSAL_FUSED_PROBE
 #define UAVSAL_FUSED_PROBE 0      /* timing experiments only (tools/fused_probe.py): 1 no expand MFMA, 2 no depthwise taps,
                                      4 no projection MFMA, 8 every chunk uses chunk 0's weights, 16 no barriers, 32 no E writes */
+#endif
+
+#ifdef UAVSAL_FIR_STAMPS      // diagnostic build only (tools/fir_stamps.py): s_memtime at the phase boundaries of a mid-grid workgroup, wave 0,
+                              // every stamp behind a full s_waitcnt (the phases are serialised by the stamps: costs, not overlap)
+__device__ unsigned long long g_fir_stamps[128];
+#define FIR_STAMP(i) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
+                       if (blockIdx.x == gridDim.x / 2 && tid == 0) g_fir_stamps[i] = __builtin_amdgcn_s_memtime(); }
+#else
+#define FIR_STAMP(i)
 #endif
 
 template <int CIN, int HID, int COUT, int S, bool EXPAND, int HC, int TX, int PT>
@@ -120,6 +127,7 @@ __global__ __launch_bounds__(256, 2) void fused_ir_kernel(const FusedK p) {
     const int oy0 = ty * TY, ox0 = tx * TX;
     const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
     const float* inb = p.in + (size_t)n * p.H * p.W * p.ldi;
+    FIR_STAMP(0)
 
     // halo slot -> input pixel; false for the pad slots
     auto slot_pixel = [&](int slot, int& gy, int& gx) -> bool {
@@ -186,32 +194,45 @@ __global__ __launch_bounds__(256, 2) void fused_ir_kernel(const FusedK p) {
         }
     }
 
+    FIR_STAMP(1)
     f32x4 acc_o[PT][NCT];
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) acc_o[pt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // ---- the block's weights -> LDS, once per workgroup (16-byte pieces; every segment is a multiple of 4 floats)
+    // ---- weight staging: items of 16 bytes; item -> (source address in chunk 0, floats between chunks, offset in the chunk block)
     constexpr bool STAGE_W = Cfg::STAGE_W;
+    constexpr int HQ = HC / 4, NI_W1 = CIN * HQ, NI_V = HQ, NI_WD = 9 * HQ, NI_W2 = HC * COUT / 4;
+    constexpr int NITEM = NI_W1 + 2 * NI_V + NI_WD + 2 * NI_V + NI_W2, WROUNDS = (NITEM + 255) / 256;
     float* const wl = lds + Cfg::WBASE;
+    const float* wsrc[STAGE_W ? WROUNDS : 1];
+    int wdst[STAGE_W ? WROUNDS : 1], wstep[STAGE_W ? WROUNDS : 1];
+    f32x4 wreg[STAGE_W ? WROUNDS : 1];
     if (STAGE_W) {
-        auto copy_seg = [&](const float* src, int dst_off, int nfloat) {
-            for (int i = tid * 4; i < nfloat; i += 256 * 4) *reinterpret_cast<f32x4*>(wl + dst_off + i) = *reinterpret_cast<const f32x4*>(src + i);
-        };
-        copy_seg(p.w1, 0, CIN * HID);
-        copy_seg(p.s1, Cfg::WOFF_S1, HID);
-        copy_seg(p.b1, Cfg::WOFF_B1, HID);
-        copy_seg(p.wd, Cfg::WOFF_WD, 9 * HID);
-        copy_seg(p.sd, Cfg::WOFF_SD, HID);
-        copy_seg(p.bd, Cfg::WOFF_BD, HID);
-        copy_seg(p.w2, Cfg::WOFF_W2, HID * COUT);
+#pragma unroll
+        for (int r = 0; r < WROUNDS; ++r) {
+            int it = tid + 256 * r;
+            wsrc[r] = nullptr; wdst[r] = 0; wstep[r] = HC;
+            if (it < NI_W1) { const int k = it / HQ, q = it - k * HQ; wsrc[r] = p.w1 + (size_t)k * HID + 4 * q; wdst[r] = k * HC + 4 * q; }
+            else if ((it -= NI_W1) < NI_V) { wsrc[r] = p.s1 + 4 * it; wdst[r] = Cfg::CW_S1 + 4 * it; }
+            else if ((it -= NI_V) < NI_V) { wsrc[r] = p.b1 + 4 * it; wdst[r] = Cfg::CW_B1 + 4 * it; }
+            else if ((it -= NI_V) < NI_WD) { const int tp = it / HQ, q = it - tp * HQ; wsrc[r] = p.wd + (size_t)tp * HID + 4 * q; wdst[r] = Cfg::CW_WD + tp * HC + 4 * q; }
+            else if ((it -= NI_WD) < NI_V) { wsrc[r] = p.sd + 4 * it; wdst[r] = Cfg::CW_SD + 4 * it; }
+            else if ((it -= NI_V) < NI_V) { wsrc[r] = p.bd + 4 * it; wdst[r] = Cfg::CW_BD + 4 * it; }
+            else if ((it -= NI_V) < NI_W2) { wsrc[r] = p.w2 + 4 * it; wdst[r] = Cfg::CW_W2 + 4 * it; wstep[r] = HC * COUT; }
+        }
+#pragma unroll
+        for (int r = 0; r < WROUNDS; ++r)
+            if (wsrc[r]) *reinterpret_cast<f32x4*>(wl + wdst[r]) = *reinterpret_cast<const f32x4*>(wsrc[r]);      // chunk 0
         __syncthreads();
     }
-    const float* const g_w1 = STAGE_W ? nullptr : p.w1;
+    const float* const g_w1 = p.w1;
+    FIR_STAMP(2)
 
     for (int ch = 0; ch < NCH; ++ch) {
         const int c0 = (UAVSAL_FUSED_PROBE & 8) ? 0 : ch * HC;
+        const float* const wc = wl + (ch & 1) * Cfg::CW_F;             // this chunk's staged weights
         // ---- this chunk's weights, as MFMA A fragments / per-lane constants (global loads, cache-resident) ----
         float w1f[EXPAND ? NCTE : 1][EXPAND ? KE : 1];
         f32x4 s1q[EXPAND ? NCTE : 1], b1q[EXPAND ? NCTE : 1];
@@ -220,10 +241,10 @@ __global__ __launch_bounds__(256, 2) void fused_ir_kernel(const FusedK p) {
             for (int ct = 0; ct < NCTE; ++ct) {
 #pragma unroll
                 for (int s = 0; s < KE; ++s)
-                    w1f[ct][s] = STAGE_W ? wl[(lq * KE + s) * HID + c0 + ct * 16 + l15] : g_w1[(size_t)(lq * KE + s) * HID + c0 + ct * 16 + l15];
-                s1q[ct] = STAGE_W ? *reinterpret_cast<const f32x4*>(wl + Cfg::WOFF_S1 + c0 + ct * 16 + 4 * lq)
+                    w1f[ct][s] = STAGE_W ? wc[(lq * KE + s) * HC + ct * 16 + l15] : g_w1[(size_t)(lq * KE + s) * HID + c0 + ct * 16 + l15];
+                s1q[ct] = STAGE_W ? *reinterpret_cast<const f32x4*>(wc + Cfg::CW_S1 + ct * 16 + 4 * lq)
                                   : *reinterpret_cast<const f32x4*>(p.s1 + c0 + ct * 16 + 4 * lq);
-                b1q[ct] = STAGE_W ? *reinterpret_cast<const f32x4*>(wl + Cfg::WOFF_B1 + c0 + ct * 16 + 4 * lq)
+                b1q[ct] = STAGE_W ? *reinterpret_cast<const f32x4*>(wc + Cfg::CW_B1 + ct * 16 + 4 * lq)
                                   : *reinterpret_cast<const f32x4*>(p.b1 + c0 + ct * 16 + 4 * lq);
             }
         }
@@ -232,10 +253,10 @@ __global__ __launch_bounds__(256, 2) void fused_ir_kernel(const FusedK p) {
         for (int q = 0; q < CQ; ++q) {
 #pragma unroll
             for (int tp = 0; tp < 9; ++tp)
-                wdq[tp][q] = STAGE_W ? *reinterpret_cast<const f32x4*>(wl + Cfg::WOFF_WD + tp * HID + c0 + lq * CPL + 4 * q)
+                wdq[tp][q] = STAGE_W ? *reinterpret_cast<const f32x4*>(wc + Cfg::CW_WD + tp * HC + lq * CPL + 4 * q)
                                      : *reinterpret_cast<const f32x4*>(p.wd + (size_t)tp * HID + c0 + lq * CPL + 4 * q);
-            sdq[q] = STAGE_W ? *reinterpret_cast<const f32x4*>(wl + Cfg::WOFF_SD + c0 + lq * CPL + 4 * q) : *reinterpret_cast<const f32x4*>(p.sd + c0 + lq * CPL + 4 * q);
-            bdq[q] = STAGE_W ? *reinterpret_cast<const f32x4*>(wl + Cfg::WOFF_BD + c0 + lq * CPL + 4 * q) : *reinterpret_cast<const f32x4*>(p.bd + c0 + lq * CPL + 4 * q);
+            sdq[q] = STAGE_W ? *reinterpret_cast<const f32x4*>(wc + Cfg::CW_SD + lq * CPL + 4 * q) : *reinterpret_cast<const f32x4*>(p.sd + c0 + lq * CPL + 4 * q);
+            bdq[q] = STAGE_W ? *reinterpret_cast<const f32x4*>(wc + Cfg::CW_BD + lq * CPL + 4 * q) : *reinterpret_cast<const f32x4*>(p.bd + c0 + lq * CPL + 4 * q);
         }
         float w2f[NCT][CPL];
 #pragma unroll
@@ -243,9 +264,15 @@ __global__ __launch_bounds__(256, 2) void fused_ir_kernel(const FusedK p) {
             const int co = ct * 16 + l15;
 #pragma unroll
             for (int s = 0; s < CPL; ++s)
-                w2f[ct][s] = co < COUT ? (STAGE_W ? wl[Cfg::WOFF_W2 + (c0 + lq * CPL + s) * COUT + co] : p.w2[(size_t)(c0 + lq * CPL + s) * COUT + co]) : 0.f;
+                w2f[ct][s] = co < COUT ? (STAGE_W ? wc[Cfg::CW_W2 + (lq * CPL + s) * COUT + co] : p.w2[(size_t)(c0 + lq * CPL + s) * COUT + co]) : 0.f;
+        }
+        if (STAGE_W && ch + 1 < NCH) {           // the next chunk's weights: global loads now, LDS writes in front of this chunk's barrier
+#pragma unroll
+            for (int r = 0; r < WROUNDS; ++r)
+                if (wsrc[r]) wreg[r] = *reinterpret_cast<const f32x4*>(wsrc[r] + (size_t)(ch + 1) * wstep[r]);
         }
 
+        FIR_STAMP(8 + 5 * ch)
         float* eb = lds + (NBUF == 2 ? (ch & 1) * EBUF : 0);
         if (EXPAND) {
             if (NBUF == 1 && ch > 0 && !(UAVSAL_FUSED_PROBE & 16)) __syncthreads();       // the previous chunk's depthwise reads are done
@@ -274,7 +301,14 @@ __global__ __launch_bounds__(256, 2) void fused_ir_kernel(const FusedK p) {
                     if (!(UAVSAL_FUSED_PROBE & 32) || e[ct].x == 123.f) *reinterpret_cast<f32x4*>(eb + (size_t)(ct * 4 + lq) * PLANE + (rt * 16 + l15) * SLOTF) = e[ct];
             }
         }
-        if (!(UAVSAL_FUSED_PROBE & 16)) __syncthreads();          // E (or the staged input) visible
+        if (STAGE_W && ch + 1 < NCH) {
+#pragma unroll
+            for (int r = 0; r < WROUNDS; ++r)
+                if (wsrc[r]) *reinterpret_cast<f32x4*>(wl + ((ch + 1) & 1) * Cfg::CW_F + wdst[r]) = wreg[r];
+        }
+        FIR_STAMP(9 + 5 * ch)
+        if (!(UAVSAL_FUSED_PROBE & 16)) __syncthreads();          // E (or the staged input) and the next chunk's weights visible
+        FIR_STAMP(10 + 5 * ch)
         // ---- depthwise 3x3 (stride S) + BN + ReLU6, then the projection with the lane's values as B fragment ----
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) {
@@ -294,6 +328,7 @@ __global__ __launch_bounds__(256, 2) void fused_ir_kernel(const FusedK p) {
                 }
 #pragma unroll
             for (int q = 0; q < CQ; ++q) dq[q] = relu6_4(dq[q] * sdq[q] + bdq[q]);
+            if (pt == PT - 1) { FIR_STAMP(11 + 5 * ch) }
 #pragma unroll
             for (int s = 0; s < CPL; ++s)
 #pragma unroll
@@ -301,7 +336,9 @@ __global__ __launch_bounds__(256, 2) void fused_ir_kernel(const FusedK p) {
                     if (UAVSAL_FUSED_PROBE & 4) acc_o[pt][ct][s & 3] += w2f[ct][s] * dq[s >> 2][s & 3];
                     else acc_o[pt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2f[ct][s], dq[s >> 2][s & 3], acc_o[pt][ct], 0, 0, 0);
         }
+        FIR_STAMP(12 + 5 * ch)
     }
+    FIR_STAMP(3)
 
     // ---- epilogue: BN (linear), residual, store: lane holds output channels ct*16 + 4*lq .. +3 of pixel l15 of its tiles ----
 #pragma unroll
@@ -320,6 +357,7 @@ __global__ __launch_bounds__(256, 2) void fused_ir_kernel(const FusedK p) {
             *reinterpret_cast<f32x4*>(p.out + opix * p.ldo + co) = v;
         }
     }
+    FIR_STAMP(4)
 }
 
 template <int CIN, int HID, int COUT, int S, bool EXPAND, int HC, int TX, int PT>
@@ -390,6 +428,12 @@ int dispatch(const uavsal_fused_ir_desc* d, hipStream_t s, bool launch) {
 // fused_mid.hip: the GEMM-shaped kernel for the mid-channel blocks (Cin 64 / 96); 2 = instance exists
 int uavsal_fused_mid_dispatch(const uavsal_fused_ir_desc* d, hipStream_t s, bool launch);
 
+#ifdef UAVSAL_FIR_STAMPS
+extern "C" int uavsal_fir_stamps(unsigned long long* dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_fir_stamps), sizeof(unsigned long long) * 128);
+}
+#endif
+
 extern "C" int uavsal_fused_ir_supported(const uavsal_fused_ir_desc* d) {
     if (!d) return 0;
     const int mid = uavsal_fused_mid_dispatch(d, nullptr, false);
@@ -405,11 +449,9 @@ extern "C" int uavsal_fused_ir(const uavsal_fused_ir_desc* d, uavsal_stream_t st
         !uavsal_aligned16(d->bias2) || (d->w1 && (!uavsal_aligned16(d->scale1) || !uavsal_aligned16(d->bias1))) ||
         (d->res && ((d->ldr & 3) || !uavsal_aligned16(d->res))))
         return UAVSAL_EALIGN;
+    if ((d->w1 && !uavsal_aligned16(d->w1)) || !uavsal_aligned16(d->w2)) return UAVSAL_EALIGN;      // staged in 16-byte pieces
     if (d->tile < 0 || d->tile > 2) return UAVSAL_EINVAL;
     if (d->res && (d->ldr < d->Cout || d->stride != 1 || d->Cin != d->Cout)) return UAVSAL_ESHAPE;
-    if (uavsal_fused_mid_dispatch(d, nullptr, false)) {
-        if (!uavsal_aligned16(d->w1) || !uavsal_aligned16(d->w2)) return UAVSAL_EALIGN;      // staged by 16-byte LDS-DMA requests
-        return uavsal_fused_mid_dispatch(d, (hipStream_t)stream, true);
-    }
+    if (uavsal_fused_mid_dispatch(d, nullptr, false)) return uavsal_fused_mid_dispatch(d, (hipStream_t)stream, true);
     return dispatch(d, (hipStream_t)stream, true);
 }
