@@ -643,6 +643,24 @@ def main():
                     "note": "independent requests round-robin on 2 host streams / model replicas; per-request work unchanged"}
             except Exception as e:
                 result["extra_two_requests_in_flight"] = {"error": repr(e)[:200]}
+        if not args.no_extra:
+            # the SAME inputs handed over the way priors.get_bias hands them: the synthetic priors -- like the reference caller's
+            # (np.repeat of one prior file over the frames, utils_data.py:466-467, 601-602) -- are one map set for every frame; as
+            # a zero-stride view the model runs its two prior nets on one frame instead of on all C x T (model.dedupe_priors).
+            # `value` above does NOT use this: its priors are materialised per frame, as the reference's caller materialises them
+            try:
+                if all(bool((c[:, :1] == c).all()) and bool((c[:1] == c).all()) for c in cb):
+                    log("extra: priors as one broadcast map set")
+                    cbv = [c[:1, :1].expand(C, T, -1, -1, -1) for c in cb]
+                    dts = timed_steps(lambda: model.forward_clips(x, cbv, state), args.steps, 3, False, device)
+                    ov, _ = model.forward_clips(x, cbv, state)
+                    result["extra_frame_invariant_priors"] = {
+                        "value": round(C * T * args.steps / dts, 2), "unit": "frames/s", "ms_per_step": round(dts / args.steps * 1e3, 4),
+                        "max_abs_vs_value_path": float("%.3e" % (ov - last["out"]).abs().max().item()),
+                        "note": "same frames and the same prior VALUES, handed over as a zero-stride view of one map set "
+                                "(priors.get_bias default): prior nets on 1 frame + broadcast instead of on every frame"}
+            except Exception as e:
+                result["extra_frame_invariant_priors"] = {"error": repr(e)[:200]}
 
     if rank == 0:
         print(json.dumps(result), flush=True)

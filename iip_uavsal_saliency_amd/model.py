@@ -185,6 +185,10 @@ class UAVSal(nn.Module):
         # (valid until the next call overwrites it) and passing it back costs nothing.  Default False keeps the
         # reference's ownership rule: fresh tensors, never aliased (Demo_Test.py:86).
         self.persistent_state = False
+        # Priors handed over as ONE map set broadcast over the frames (zero frame stride: what `priors.get_bias` returns -- the
+        # reference's caller repeats one prior file over all frames, utils_data.py:466-467, 601-602): the two prior nets run on
+        # one frame instead of on every frame.  Decided from the strides, never from the values; False: always per frame.
+        self.dedupe_priors = True
         self.max_engines = 4            # launch plans kept per model (LRU); packed weights are shared by all
         self.check_weight_versions = True   # rebuild plans when a parameter/buffer was modified in place
         self.sfnet = uavsal_srfnet_aspp(cnn_type, last_channel=planes)
@@ -262,7 +266,14 @@ class UAVSal(nn.Module):
             self._drop_engines()
         return super().train(mode)
 
-    def _engine(self, device, n_seq, seq_len, H, W, ctx_mode, taps=False, in_dtype=torch.float32, sync_default=True):
+    @staticmethod
+    def frame_invariant(cb, frame_dims=1):
+        """Are the caller's priors ONE map set for every frame -- structurally: every frame dimension of both tensors is a
+        broadcast (stride 0, e.g. `maps[None].expand(n, -1, -1, -1)`, which is what `priors.get_bias` returns) or has one entry?
+        Never decided from the values: materialised copies (`np.repeat`, `.repeat`, `.contiguous()`) take the general plan."""
+        return all(all(t.shape[d] == 1 or t.stride(d) == 0 for d in range(frame_dims)) for t in cb)
+
+    def _engine(self, device, n_seq, seq_len, H, W, ctx_mode, taps=False, in_dtype=torch.float32, sync_default=True, static_priors=False):
         from .engine import Engine
         if self.check_weight_versions:
             if self._wversion is None:
@@ -277,7 +288,7 @@ class UAVSal(nn.Module):
                ctx_mode, self.precision, bool(taps), in_dtype, bool(self.use_graph), self.rnn_type, self.fuse_dw, bool(self.use_lanes),
                bool(self.stream_k), bool(self.persistent_state), tuple(getattr(self, "_sk_debug", (0, 0))),
                self.presplit, bool(self.fuse_blocks), bool(getattr(self, "winograd", True)), getattr(self, "winograd_r", None),
-               tuple(sorted((getattr(self, "prec_overrides", None) or {}).items())))
+               tuple(sorted((getattr(self, "prec_overrides", None) or {}).items())), bool(static_priors))
         eng = self._engines.get(key)
         if eng is None:
             while len(self._engines) >= max(1, int(self.max_engines)):
@@ -287,7 +298,7 @@ class UAVSal(nn.Module):
                          ctx_T=key[5], ctx_mode=ctx_mode, precision=self.precision, taps=taps,
                          in_dtype=in_dtype, use_graph=self.use_graph, fuse_dw=self.fuse_dw,
                          use_lanes=self.use_lanes, stream_k=self.stream_k, persistent=self.persistent_state,
-                         wcache=self._wshared.setdefault(str(torch.device(device)), {}))
+                         wcache=self._wshared.setdefault(str(torch.device(device)), {}), static_priors=static_priors)
             self._engines[key] = eng
         else:
             self._engines.move_to_end(key)
@@ -319,7 +330,8 @@ class UAVSal(nn.Module):
         if n % self.time_dims:
             raise RuntimeError("shape '[%d, %d, ...]' is invalid for input of %d frames (model.py:357)" % (
                 n // self.time_dims, self.time_dims, n))
-        eng = self._engine(x.device, 1, n, H, W, "tile", taps is not None, x.dtype)
+        static = self.dedupe_priors and len(cb) == 2 and n > 1 and self.frame_invariant(cb, 1)
+        eng = self._engine(x.device, 1, n, H, W, "tile", taps is not None, x.dtype, static_priors=static)
         h, w = eng.h, eng.w
         self._check_cb(cb, n, h, w)
         st, cst = None, None
@@ -347,7 +359,8 @@ class UAVSal(nn.Module):
         C, T, _, H, W = x.shape
         if T < 2:
             raise RuntimeError("each clip needs at least 2 frames (reference teConv_sub, model.py:194)")
-        eng = self._engine(x.device, C, T, H, W, "clip", taps is not None, x.dtype, sync_default=False)
+        static = self.dedupe_priors and len(cb) == 2 and cb[0].dim() == 5 and cb[1].dim() == 5 and self.frame_invariant(cb, 2)
+        eng = self._engine(x.device, C, T, H, W, "clip", taps is not None, x.dtype, sync_default=False, static_priors=static)
         h, w = eng.h, eng.w
         self._check_cb([cb[0].reshape(C * T, *cb[0].shape[2:]), cb[1].reshape(C * T, *cb[1].shape[2:])], C * T, h, w)
         cst = None

@@ -108,19 +108,23 @@ def get_ob_priors(path: str, b_s: int = 2, shape_r: int = 45, shape_c: int = 80,
 
 def get_bias(bias_type=(1, 1, 1), batch_size: int = 2, shape_r: int = 45, shape_c: int = 80,
              ob_prior_path: Optional[str] = None, gauss_prior_path: Optional[str] = None,
-             device="cuda", quirk: bool = True) -> List[torch.Tensor]:
+             device="cuda", quirk: bool = True, broadcast: bool = True) -> List[torch.Tensor]:
     """`[x_cb_gauss [n,8,h,w], x_cb_ob [n,20,h,w]]` float32 on `device` (Demo_Test.py:14-27).  `quirk`: see the module
-    docstring (resized priors become {0,1} maps in the reference; False keeps the bilinear floats)."""
+    docstring (resized priors become {0,1} maps in the reference; False keeps the bilinear floats).
+    `broadcast` (default): the n frames are a zero-stride view of ONE map set on the device -- the same values as the
+    reference's `np.repeat` (utils_data.py:466-467, 601-602) without n copies, and `UAVSal.forward` recognises the view and
+    runs its prior nets once (model.dedupe_priors); False materialises the n copies as the reference does."""
+    def frames(maps_hwc):
+        t = torch.from_numpy(np.ascontiguousarray(maps_hwc.transpose(2, 0, 1))).float().to(device)[None]
+        return t.expand(batch_size, -1, -1, -1) if broadcast else t.repeat(batch_size, 1, 1, 1)
     if bias_type[0]:
-        g = torch.from_numpy(get_guasspriors(batch_size, shape_r, shape_c, 8, gauss_prior_path, quirk)
-                             .transpose(0, 3, 1, 2).copy()).float()
+        g = frames(get_guasspriors(1, shape_r, shape_c, 8, gauss_prior_path, quirk)[0])
     else:
-        g = torch.tensor([]).float()
+        g = torch.tensor([]).float().to(device)
     if bias_type[1]:
         if ob_prior_path is None:
             raise ValueError("ob_prior_path (e.g. UAV2_ob_priors_train.mat) is required when bias_type[1] is set")
-        o = torch.from_numpy(get_ob_priors(ob_prior_path, batch_size, shape_r, shape_c, quirk)
-                             .transpose(0, 3, 1, 2).copy()).float()
+        o = frames(get_ob_priors(ob_prior_path, 1, shape_r, shape_c, quirk)[0])
     else:
-        o = torch.tensor([]).float()
-    return [g.to(device), o.to(device)]
+        o = torch.tensor([]).float().to(device)
+    return [g, o]

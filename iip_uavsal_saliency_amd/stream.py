@@ -58,8 +58,9 @@ def predict_video(model, frames_u8: torch.Tensor, gauss_prior: torch.Tensor, ob_
         for i in range(steps):
             x = frames_u8[i * group:(i + 1) * group]
             n = x.shape[0]
-            cb = [gauss_prior.to(dev).unsqueeze(0).expand(n, -1, -1, -1).contiguous(),
-                  ob_prior.to(dev).unsqueeze(0).expand(n, -1, -1, -1).contiguous()]
+            # one map set for every frame, handed over as a zero-stride view: the model runs its prior nets once per call
+            # (model.dedupe_priors) instead of once per frame
+            cb = [gauss_prior.to(dev).unsqueeze(0).expand(n, -1, -1, -1), ob_prior.to(dev).unsqueeze(0).expand(n, -1, -1, -1)]
             out, st = model(x, cb, state)
             # persistent mode: st[0] is a view of the engine's state buffer (valid until the next call, which
             # recognises it by address); a shorter last group runs on another plan, which loads it as a tensor

@@ -403,6 +403,46 @@ def test_uint8_frames_match_float_frames(hip_model):
     assert (a - b).abs().max().item() <= 1e-4
 
 
+def test_frame_invariant_priors_run_the_prior_nets_once(hip_model, oracle):
+    """The reference's caller hands the SAME prior maps to every frame (np.repeat, utils_data.py:466-467, 601-602).  Given as a
+    zero-stride view (priors.get_bias's default) the plan runs the two prior nets on one frame and broadcasts their output; given
+    materialised -- or with model.dedupe_priors off -- every frame goes through them.  Same maps either way (the one-frame launches
+    may pick other tiles: summation order), both within the parity bound of the oracle."""
+    n, H, W = 8, 96, 160
+    x, cb = make_inputs(n, H, W)
+    assert all(torch.equal(c[0], c[k]) for c in cb for k in range(n))            # synth priors: one map set per call, like get_bias
+    hip_model.time_dims, hip_model.precision = 4, "f32"
+    xc = x.cuda()
+    mat = [c.cuda() for c in cb]
+    view = [c[:1].cuda().expand(n, -1, -1, -1) for c in cb]
+    out_g, st_g = hip_model(xc, mat, None)
+    out_s, st_s = hip_model(xc, view, None)
+    engs = {e.static_priors: e for e in hip_model._engines.values() if e.N == n and e.H == H and e.prec_name == "f32"}
+    assert set(engs) == {False, True}
+    names = lambda e: [m["name"] for m in e.ops_meta]
+    assert "gauss.bcast" in names(engs[True]) and "ob.bcast" in names(engs[True]) and "gauss.bcast" not in names(engs[False])
+    assert len(names(engs[True])) == len(names(engs[False])) + 2
+    assert (out_s - out_g).abs().max().item() <= 1e-4 and (st_s[0] - st_g[0]).abs().max().item() <= 1e-4
+    oracle.time_dims = 4
+    ro, rs = oracle(x, cb, None)
+    assert (out_s.cpu() - ro).abs().max().item() <= MAP_TOL["f32"] and (st_s[0].cpu() - rs[0]).abs().max().item() <= STATE_TOL["f32"]
+    hip_model.dedupe_priors = False
+    try:
+        out_off, _ = hip_model(xc, view, None)                                   # the view through the general plan: bit for bit
+    finally:
+        hip_model.dedupe_priors = True
+    assert torch.equal(out_off, out_g)
+    # forward_clips: [C, T, ., h, w] broadcast over clips AND frames
+    x5 = xc.view(2, 4, 3, H, W)
+    v5 = [c[:1].cuda()[None].expand(2, 4, -1, -1, -1) for c in cb]
+    m5 = [c.cuda().view(2, 4, *c.shape[1:]) for c in cb]
+    o5s, s5s = hip_model.forward_clips(x5, v5, None)
+    o5g, s5g = hip_model.forward_clips(x5, m5, None)
+    hip_model.check_errors()
+    assert any(e.static_priors and e.n_seq == 2 for e in hip_model._engines.values())
+    assert (o5s - o5g).abs().max().item() <= 1e-4 and (s5s - s5g).abs().max().item() <= 1e-4
+
+
 def test_graph_replay_matches_launch_loop(hip_model):
     x, cb = make_inputs(4, 96, 160)
     a, sa = _run_hip(hip_model, 4, "f16x3", x, cb)

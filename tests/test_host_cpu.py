@@ -324,6 +324,19 @@ def test_mat_reader_and_priors(golden_dir):
                          device="cpu")
     assert tuple(cb[0].shape) == (3, 8, 45, 80) and tuple(cb[1].shape) == (3, 20, 45, 80)
     assert cb[0].dtype == torch.float32 and float(cb[1].max()) <= 1.0
+    # ... as a zero-stride view of ONE map set (what lets the model run its prior nets once per call); same values materialised
+    from iip_uavsal_saliency_amd import UAVSal
+    rep = priors.get_bias([1, 1, 1], 3, 45, 80, ob_prior_path=os.path.join(golden_dir, "UAV2_ob_priors_train.npz"),
+                          device="cpu", broadcast=False)
+    assert cb[0].stride(0) == 0 and cb[1].stride(0) == 0 and rep[0].stride(0) != 0
+    assert torch.equal(cb[0], rep[0]) and torch.equal(cb[1], rep[1])
+    assert UAVSal.frame_invariant(cb, 1) and not UAVSal.frame_invariant(rep, 1)
+    assert not UAVSal.frame_invariant([cb[0], rep[1]], 1)                       # both tensors must be broadcasts
+    assert not UAVSal.frame_invariant([c.contiguous() for c in cb], 1)          # never decided from the values
+    five = [c[None].expand(2, -1, -1, -1, -1) for c in cb]                      # forward_clips: [C, T, ., h, w]
+    assert UAVSal.frame_invariant(five, 2)
+    per_clip = [torch.stack([c[0], c[0] + 1])[:, None].expand(-1, 3, -1, -1, -1) for c in cb]     # one map set PER CLIP: general plan
+    assert not UAVSal.frame_invariant(per_clip, 2)
 
 
 def test_priors_resize_path_letterbox_geometry_and_uint8_truncation(golden_dir):
