@@ -9,83 +9,90 @@ namespace {
 // ---------------------------------------------------------------- stem 3x3 s2, 3 -> 32
 struct StemK {
     const float* in; const uint8_t* in_u8; const float* w; const float* scale; const float* bias;
-    float* out; int ldo, H, W, Ho, Wo; long long total;
+    float* out; int ldo, H, W, Ho, Wo, tiles_x, tiles_y;
     float mean[3], stdv[3];
 };
 
+// A workgroup owns ST_TY x ST_TX output pixels of one image.  The (2 ST_TY + 1) x (2 ST_TX + 1) x 3 input patch is staged in LDS by
+// coalesced loads (consecutive lanes = consecutive columns of a row; uint8 frames are normalised here), then a thread computes 8
+// pixels x 4 channels out of LDS: a tap's 4 weights are read once for 8 pixels, the 17 input columns of a (channel, kernel row) as
+// four ds_read_b128 + one b32, and eight lanes write the 128 contiguous bytes of an output pixel.  (Round 2-4 form: every thread fetched its 81 inputs with 4-byte global loads, four lanes per
+// address and 32 bytes between neighbours -- 324 wave-level loads per 256 pixels against 56 now; the kernel sat at 2.7 TB/s on
+// its load instructions, not on bytes or FMAs: 48 v_pk_fma_f32 per loop body.)
+constexpr int ST_TY = 4, ST_TX = 64, ST_IH = 2 * ST_TY + 1, ST_IW = 2 * ST_TX + 1, ST_PITCH = 132, ST_ROWS = 3 * ST_IH;
+static_assert(ST_PITCH >= ST_IW && ST_PITCH % 4 == 0 && ST_TY * ST_TX == 256, "stem tile");
+
 __global__ __launch_bounds__(256) void stem_kernel(const StemK p) {
-    __shared__ float wsh[27 * 32];
-    __shared__ float ssh[32], bsh[32];
-    for (int i = threadIdx.x; i < 27 * 32; i += 256) wsh[i] = p.w[i];
-    if (threadIdx.x < 32) { ssh[threadIdx.x] = p.scale[threadIdx.x]; bsh[threadIdx.x] = p.bias[threadIdx.x]; }
-    __syncthreads();
-    // thread = (4 consecutive output pixels along x, group of 8 channels): a tap's 8 weights are read from
-    // LDS once for 4 pixels (one pixel per thread made this kernel LDS-read-bound: 60 us for 81 MB)
-    const long long item = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (item >= p.total) return;
-    const int g = (int)(item & 3);
-    long long t = item >> 2;
-    const int Wq = (p.Wo + 3) >> 2;
-    const int oxq = (int)(t % Wq); t /= Wq;
-    const int oy = (int)(t % p.Ho);
-    const int n = (int)(t / p.Ho);
-    const int ox0 = oxq * 4;
-    float acc[4][8];
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[q][j] = 0.f;
+    __shared__ __attribute__((aligned(16))) float wsh[27 * 32];
+    __shared__ __attribute__((aligned(16))) float ssh[32], bsh[32];
+    __shared__ __attribute__((aligned(16))) float xsh[ST_ROWS * ST_PITCH];
+    const int tid = threadIdx.x;
+    int b = blockIdx.x;
+    const int tx = b % p.tiles_x; b /= p.tiles_x;
+    const int ty = b % p.tiles_y;
+    const int n = b / p.tiles_y;
+    const int oy0 = ty * ST_TY, ox0 = tx * ST_TX;
+    const int iy0 = 2 * oy0 - 1, ix0 = 2 * ox0 - 1;
     const size_t plane = (size_t)p.H * p.W;
-    // NOT unrolled over (input channel, kernel row): fully unrolled, hipcc hoists all 81 input loads and the kernel
-    // needs > 256 VGPRs -- one wave per SIMD, 59 us; with the two outer loops rolled it is 80 VGPRs, six waves, 29 us
-#ifndef UAVSAL_STEM_UNROLL
-#define UAVSAL_STEM_UNROLL 1
-#endif
-#pragma unroll UAVSAL_STEM_UNROLL
-    for (int ci = 0; ci < 3; ++ci) {
-        const float mu = p.in_u8 ? p.mean[ci] : 0.f, sd = p.in_u8 ? p.stdv[ci] : 1.f;
-#ifndef UAVSAL_STEM_UNROLL_KY
-#define UAVSAL_STEM_UNROLL_KY 1
-#endif
-#pragma unroll UAVSAL_STEM_UNROLL_KY
-        for (int ky = 0; ky < 3; ++ky) {
-            const int iy = oy * 2 - 1 + ky;
-            const bool yok = iy >= 0 && iy < p.H;
-            const size_t rowi = ((size_t)n * 3 + ci) * plane + (size_t)(yok ? iy : 0) * p.W;
-            float v[9];                                  // input columns 2*ox0-1 .. 2*ox0+7
+    constexpr int NST = (ST_ROWS * ST_PITCH + 255) / 256;
+    float st[NST];
 #pragma unroll
-            for (int c = 0; c < 9; ++c) {
-                const int ix = ox0 * 2 - 1 + c;
-                float x = 0.f;
-                if (yok && ix >= 0 && ix < p.W) {
-                    if (p.in_u8) x = ((float)p.in_u8[rowi + ix] / 255.0f - mu) / sd;
-                    else x = p.in[rowi + ix];
-                }
-                v[c] = x;
+    for (int i = 0; i < NST; ++i) {                      // all the loads of a thread first, then its LDS writes
+        const int idx = tid + 256 * i;
+        const int r = idx / ST_PITCH, c = idx - r * ST_PITCH;
+        const int ci = r / ST_IH, iy = iy0 + (r - ci * ST_IH), ix = ix0 + c;
+        float x = 0.f;
+        if (r < ST_ROWS && c < ST_IW && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+            const size_t at = ((size_t)n * 3 + ci) * plane + (size_t)iy * p.W + ix;
+            if (p.in_u8) x = ((float)p.in_u8[at] / 255.0f - p.mean[ci]) / p.stdv[ci];
+            else x = p.in[at];
+        }
+        st[i] = x;
+    }
+    for (int i = tid; i < 27 * 32; i += 256) wsh[i] = p.w[i];
+    if (tid < 32) { ssh[tid] = p.scale[tid]; bsh[tid] = p.bias[tid]; }
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+        const int idx = tid + 256 * i;
+        if (idx < ST_ROWS * ST_PITCH) xsh[idx] = st[i];
+    }
+    __syncthreads();
+    // thread = (8 consecutive output pixels of a row, 4 channels): eight lanes write the 128 contiguous bytes of a pixel
+    const int g = tid & 7, pxg = tid >> 3;
+    const int rr = pxg / (ST_TX / 8), xq = pxg - rr * (ST_TX / 8);
+    const int oy = oy0 + rr, oxb = ox0 + 8 * xq;
+    f32x4 acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int ci = 0; ci < 3; ++ci) {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const float* row = xsh + (ci * ST_IH + 2 * rr + ky) * ST_PITCH + 16 * xq;     // input columns 2*oxb-1 .. 2*oxb+15
+            float v[17];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(row + 4 * c);
+                v[4 * c] = a.x; v[4 * c + 1] = a.y; v[4 * c + 2] = a.z; v[4 * c + 3] = a.w;
             }
+            v[16] = row[16];
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
-                const float* wr = wsh + (ci * 9 + ky * 3 + kx) * 32 + g * 8;
-                float w8[8];
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(wsh + (ci * 9 + ky * 3 + kx) * 32 + g * 4);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) w8[j] = wr[j];
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[q][j] = fmaf(v[2 * q + kx], w8[j], acc[q][j]);
+                for (int q = 0; q < 8; ++q) acc[q] = w4 * v[2 * q + kx] + acc[q];
             }
         }
     }
+    if (oy >= p.Ho) return;
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(ssh + g * 4), bi = *reinterpret_cast<const f32x4*>(bsh + g * 4);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int ox = ox0 + q;
+    for (int q = 0; q < 8; ++q) {
+        const int ox = oxb + q;
         if (ox >= p.Wo) break;
-        float* o = p.out + (((size_t)n * p.Ho + oy) * p.Wo + ox) * p.ldo + g * 8;
-        float r[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) r[j] = fminf(fmaxf(acc[q][j] * ssh[g * 8 + j] + bsh[g * 8 + j], 0.f), 6.f);
-        *reinterpret_cast<f32x4*>(o) = (f32x4){r[0], r[1], r[2], r[3]};
-        *reinterpret_cast<f32x4*>(o + 4) = (f32x4){r[4], r[5], r[6], r[7]};
+        f32x4 r = acc[q] * sc + bi;
+        r.x = fminf(fmaxf(r.x, 0.f), 6.f); r.y = fminf(fmaxf(r.y, 0.f), 6.f); r.z = fminf(fmaxf(r.z, 0.f), 6.f); r.w = fminf(fmaxf(r.w, 0.f), 6.f);
+        *reinterpret_cast<f32x4*>(p.out + (((size_t)n * p.Ho + oy) * p.Wo + ox) * p.ldo + g * 4) = r;
     }
 }
 
@@ -224,9 +231,10 @@ extern "C" int uavsal_stem_conv(const uavsal_stem_desc* d, uavsal_stream_t strea
     k.in = d->in; k.in_u8 = d->in_u8; k.w = d->w; k.scale = d->scale; k.bias = d->bias; k.out = d->out;
     k.ldo = d->ldo; k.H = d->H; k.W = d->W; k.Ho = (d->H - 1) / 2 + 1; k.Wo = (d->W - 1) / 2 + 1;
     for (int i = 0; i < 3; ++i) { k.mean[i] = d->mean[i]; k.stdv[i] = d->stdv[i]; }
-    k.total = (long long)d->n_img * k.Ho * ((k.Wo + 3) / 4) * 4;      // (4 pixels along x, 8-channel group) items
-    int nblk; int e = grid_for(k.total, &nblk); if (e) return e;
-    hipLaunchKernelGGL(stem_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, k);
+    k.tiles_x = (k.Wo + ST_TX - 1) / ST_TX; k.tiles_y = (k.Ho + ST_TY - 1) / ST_TY;
+    const long long nblk = (long long)d->n_img * k.tiles_y * k.tiles_x;
+    if (nblk > 0x7fffffffLL) return UAVSAL_ESHAPE;
+    hipLaunchKernelGGL(stem_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, k);
     return uavsal_launch_status();
 }
 

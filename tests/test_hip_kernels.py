@@ -592,8 +592,9 @@ def test_depthwise(ops, case):
     assert err <= 1e-5, (case, err)       # 9 fp32 fmas per output, order may differ
 
 
-@pytest.mark.parametrize("size", [(2, 36, 64), (1, 45, 81), (2, 7, 9)])
+@pytest.mark.parametrize("size", [(2, 36, 64), (1, 45, 81), (2, 7, 9), (1, 21, 300), (2, 360, 640), (1, 1, 1), (1, 17, 129)])
 def test_stem(ops, size):
+    """(the kernel works on 4 x 64 output tiles: several tiles per row, ragged last tiles, maps smaller than a tile)"""
     n, H, W = size
     x = rnd((n, 3, H, W), 61, 2.0)
     wt = rnd((32, 3, 3, 3), 62, 0.3)
@@ -607,7 +608,7 @@ def test_stem(ops, size):
 def test_stem_uint8_normalisation(ops):
     """uint8 frames normalised on load == normalize_data (utils_data.py:43-65) then the fp32 stem."""
     from iip_uavsal_saliency_amd import synth
-    u8 = synth.synth_frames_u8(2, 24, 40)
+    u8 = synth.synth_frames_u8(2, 24, 300)
     wt = rnd((32, 3, 3, 3), 62, 0.3)
     scale = rnd((32,), 63) * 0.5 + 1.0
     bias = rnd((32,), 64)
