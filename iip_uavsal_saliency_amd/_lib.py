@@ -55,6 +55,12 @@ class DwDesc(C.Structure):
                 ("out_split", _f), ("ldos", C.c_int32)]
 
 
+class DwDotDesc(C.Structure):
+    _fields_ = [("inp", _f), ("ldi", C.c_int32), ("w9c", _f), ("scale", _f), ("bias", _f),
+                ("w2", _f), ("scale2", _f), ("bias2", _f), ("out", _f), ("ldo", C.c_int32),
+                ("n_img", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32), ("act", C.c_int32)]
+
+
 class StemDesc(C.Structure):
     _fields_ = [("inp", _f), ("in_u8", _f), ("w", _f), ("scale", _f), ("bias", _f),
                 ("out", _f), ("ldo", C.c_int32),
@@ -118,7 +124,7 @@ class WinoDesc(C.Structure):
 
 
 DESC_TYPES = [ConvDesc, DwDesc, StemDesc, BilinearDesc, TdiffDesc, TsumDesc, LayoutDesc, PostDesc, GuardDesc, CopyDesc,
-              FusedIrDesc, WinoDesc]
+              FusedIrDesc, WinoDesc, DwDotDesc]
 
 # every symbol include/uavsal_hip.h declares: (name, restype, argtypes)
 SYMBOLS = [
@@ -129,6 +135,7 @@ SYMBOLS = [
     ("uavsal_streamk_workspace_bytes", C.c_longlong, []),
     ("uavsal_conv_streamk_grid", C.c_int, [C.POINTER(ConvDesc)]),
     ("uavsal_dw3x3", C.c_int, [C.POINTER(DwDesc), C.c_void_p]),
+    ("uavsal_dw3x3_dot", C.c_int, [C.POINTER(DwDotDesc), C.c_void_p]),
     ("uavsal_dw_variant", C.c_int, [C.POINTER(DwDesc)]),
     ("uavsal_stem_conv", C.c_int, [C.POINTER(StemDesc), C.c_void_p]),
     ("uavsal_bilinear_ac", C.c_int, [C.POINTER(BilinearDesc), C.c_void_p]),
@@ -150,6 +157,7 @@ SYMBOLS = [
     ("uavsal_plan_destroy", None, [C.c_void_p]),
     ("uavsal_plan_add_conv", C.c_int, [C.c_void_p, C.POINTER(ConvDesc)]),
     ("uavsal_plan_add_dw", C.c_int, [C.c_void_p, C.POINTER(DwDesc)]),
+    ("uavsal_plan_add_dw_dot", C.c_int, [C.c_void_p, C.POINTER(DwDotDesc)]),
     ("uavsal_plan_add_stem", C.c_int, [C.c_void_p, C.POINTER(StemDesc)]),
     ("uavsal_plan_add_bilinear", C.c_int, [C.c_void_p, C.POINTER(BilinearDesc)]),
     ("uavsal_plan_add_tdiff", C.c_int, [C.c_void_p, C.POINTER(TdiffDesc)]),
@@ -190,7 +198,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.uavsal_abi_version() != 16:
+    if lib.uavsal_abi_version() != 17:
         raise RuntimeError("libuavsal_hip.so ABI version mismatch")
     for i, t in enumerate(DESC_TYPES):
         if lib.uavsal_sizeof_desc(i) != C.sizeof(t):

@@ -254,6 +254,98 @@ int launch_dw(DwK k, hipStream_t s) {
     return uavsal_launch_status();
 }
 
+// ---- depthwise 3x3 (stride 1) + BN + ReLU6 -> 1x1 projection to ONE channel + BN + activation, one launch (uavsal_dw3x3_dot) ----
+// The decoder's last block (conv_out_st = dwBlock(256 -> 1), reference model.py:333-334, 372-373) ends in a 1536 -> 1 projection:
+// a dot product per pixel.  As a GEMM (dwproj_kernel with 31 of its 32 output columns zero + a K-split reduce launch) it moved
+// the 177 MB of the expanded tensor at 2.7 TB/s; here it is the depthwise kernel above -- 4 channels per lane, a wave = 256
+// consecutive channels of a pixel per load, a 4 x 4 output patch per thread -- whose epilogue multiplies by the lane's four
+// projection weights instead of storing: the sixteen partial dot products are summed over the wave by a shuffle butterfly and
+// over the workgroup's waves (one workgroup = ALL channels of one patch, blockDim = C / 4) through LDS, in a fixed order.
+struct DwDotK {
+    const float* in; const float* w9c; const float* scale; const float* bias; const float* w2;
+    const float* scale2; const float* bias2; float* out;
+    int ldi, ldo, H, W, C4, act, tiles_x, tiles_y, nblk;
+};
+
+// (230 VGPRs: one 6-wave workgroup per CU at C = 1536.  Capped at 168 / 128 for two or three -- __launch_bounds__(512, 3 | 4), 4x4 /
+// 2x8 / 2x4 patches -- hipcc spills 29-77 registers and the launch takes 95-123 us instead of 52: profiles/r4_dw_dot.md)
+template <int TY, int TX>
+__global__ __launch_bounds__(512, 2) void dw3x3_dot_kernel(const DwDotK p) {
+    __shared__ float red[8][TY * TX];
+    int t = xcd_virtual_block(blockIdx.x, p.nblk);
+    const int tx = t % p.tiles_x; t /= p.tiles_x;
+    const int ty = t % p.tiles_y;
+    const int n = t / p.tiles_y;
+    const int c = threadIdx.x * 4;
+    f32x4 wt[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wt[k] = ld4(p.w9c + (size_t)k * (p.C4 * 4) + c);
+    const f32x4 sc = ld4(p.scale + c), bi = ld4(p.bias + c), w2 = ld4(p.w2 + c);
+    constexpr int IW = TX + 2, IH = TY + 2;
+    const int oy0 = ty * TY, ox0 = tx * TX;
+    const float* inb = p.in + (size_t)n * p.H * p.W * p.ldi + c;
+    f32x4 acc[TY][TX];
+#pragma unroll
+    for (int a = 0; a < TY; ++a)
+#pragma unroll
+        for (int b = 0; b < TX; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < IH; ++r) {
+        const int iy = oy0 - 1 + r;
+        const bool rok = iy >= 0 && iy < p.H;
+        f32x4 row[IW];
+#pragma unroll
+        for (int q = 0; q < IW; ++q) {
+            const int ix = ox0 - 1 + q;
+            const bool ok = rok && ix >= 0 && ix < p.W;
+            row[q] = ok ? ld4(inb + ((size_t)iy * p.W + ix) * p.ldi) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int a = 0; a < TY; ++a) {
+            const int ky = r - a;
+            if (ky < 0 || ky > 2) continue;
+#pragma unroll
+            for (int b = 0; b < TX; ++b)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) acc[a][b] += row[b + kx] * wt[ky * 3 + kx];
+        }
+    }
+    float part[TY * TX];
+#pragma unroll
+    for (int a = 0; a < TY; ++a)
+#pragma unroll
+        for (int b = 0; b < TX; ++b) {
+            f32x4 v = acc[a][b] * sc + bi;
+            v.x = fminf(fmaxf(v.x, 0.f), 6.f); v.y = fminf(fmaxf(v.y, 0.f), 6.f);
+            v.z = fminf(fmaxf(v.z, 0.f), 6.f); v.w = fminf(fmaxf(v.w, 0.f), 6.f);
+            part[a * TX + b] = (v.x * w2.x + v.y * w2.y) + (v.z * w2.z + v.w * w2.w);
+        }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+        for (int i = 0; i < TY * TX; ++i) part[i] += __shfl_xor(part[i], off, 64);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int i = 0; i < TY * TX; ++i) red[wave][i] = part[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < TY * TX) {
+        const int a = threadIdx.x / TX, b = threadIdx.x - a * TX;
+        const int oy = oy0 + a, ox = ox0 + b;
+        if (oy < p.H && ox < p.W) {
+            float sum = 0.f;
+            const int nw = (int)(blockDim.x >> 6);
+            for (int w = 0; w < nw; ++w) sum += red[w][threadIdx.x];
+            float z = sum * p.scale2[0] + p.bias2[0];
+            if (p.act == UAVSAL_ACT_SIGMOID) z = 1.f / (1.f + expf(-z));
+            else if (p.act == UAVSAL_ACT_RELU6) z = fminf(fmaxf(z, 0.f), 6.f);
+            p.out[(((size_t)n * p.H + oy) * p.W + ox) * p.ldo] = z;
+        }
+    }
+}
+
+
 }  // namespace
 
 extern "C" int uavsal_dw3x3(const uavsal_dw_desc* d, uavsal_stream_t stream) {
@@ -303,4 +395,29 @@ extern "C" int uavsal_dw_variant(const uavsal_dw_desc* d) {
     k.H = d->H; k.W = d->W; k.Ho = (d->H - 1) / d->stride + 1; k.Wo = (d->W - 1) / d->stride + 1;
     k.C4 = d->C / 4; k.n_img = d->n_img;
     return dw_variant(k, d->stride, d->dilation);
+}
+
+extern "C" int uavsal_dw3x3_dot(const uavsal_dw_dot_desc* d, uavsal_stream_t stream) {
+    if (!d || !d->in || !d->w9c || !d->scale || !d->bias || !d->w2 || !d->scale2 || !d->bias2 || !d->out) return UAVSAL_EINVAL;
+    if (d->n_img <= 0 || d->H <= 0 || d->W <= 0 || d->C <= 0 || d->ldo < 1) return UAVSAL_EINVAL;
+    if ((d->C & 255) || d->C > 2048) return UAVSAL_ESHAPE;          // one workgroup = all channels of a patch: whole waves, <= 512 lanes
+    if ((d->ldi & 3) || d->ldi < d->C) return UAVSAL_EALIGN;
+    if (!uavsal_aligned16(d->in) || !uavsal_aligned16(d->w9c) || !uavsal_aligned16(d->scale) || !uavsal_aligned16(d->bias) ||
+        !uavsal_aligned16(d->w2)) return UAVSAL_EALIGN;
+    if (d->act != UAVSAL_ACT_NONE && d->act != UAVSAL_ACT_RELU6 && d->act != UAVSAL_ACT_SIGMOID) return UAVSAL_ESHAPE;
+    DwDotK k;
+    k.in = d->in; k.w9c = d->w9c; k.scale = d->scale; k.bias = d->bias; k.w2 = d->w2; k.scale2 = d->scale2; k.bias2 = d->bias2;
+    k.out = d->out; k.ldi = d->ldi; k.ldo = d->ldo; k.H = d->H; k.W = d->W; k.C4 = d->C / 4; k.act = d->act;
+#ifndef UAVSAL_DWDOT_TY
+#define UAVSAL_DWDOT_TY 4
+#endif
+#ifndef UAVSAL_DWDOT_TX
+#define UAVSAL_DWDOT_TX 4
+#endif
+    k.tiles_x = (d->W + UAVSAL_DWDOT_TX - 1) / UAVSAL_DWDOT_TX; k.tiles_y = (d->H + UAVSAL_DWDOT_TY - 1) / UAVSAL_DWDOT_TY;
+    const long long nblk = (long long)d->n_img * k.tiles_y * k.tiles_x;
+    if (nblk > 0x7fffffffLL) return UAVSAL_ESHAPE;
+    k.nblk = (int)nblk;
+    hipLaunchKernelGGL((dw3x3_dot_kernel<UAVSAL_DWDOT_TY, UAVSAL_DWDOT_TX>), dim3(k.nblk), dim3(k.C4), 0, (hipStream_t)stream, k);
+    return uavsal_launch_status();
 }

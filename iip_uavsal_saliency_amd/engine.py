@@ -76,6 +76,7 @@ MID_MIN_WGS = int(os.environ.get("UAVSAL_MID_MIN_WGS", "1"))
 MID_MAX_WGS = int(os.environ.get("UAVSAL_MID_MAX_WGS", "288"))
 
 
+DW_DOT = os.environ.get("UAVSAL_DW_DOT", "1") == "1"       # 0: the one-channel projection of conv_out_st as a dwproj GEMM + reduce launch
 _TILE_OVERRIDE = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in os.environ.get("UAVSAL_TILE_OVERRIDE", "").split(",") if "=" in kv}
 
 
@@ -548,6 +549,28 @@ class Engine:
         self.ops_meta[-1]["kernel"] = L.DW_KERNEL.get(int(self.lib.uavsal_dw_variant(C.byref(d))), "dw3x3")
         self._add(self.lib.uavsal_plan_add_dw, d, "plan_add_dw(%s)" % name)
 
+    def dw_dot(self, name, a: V, dwc, dwbn, pl, plbn, out: V, act):
+        """Depthwise 3x3 + BN + ReLU6 -> projection to ONE channel + BN + act as one bandwidth-bound launch (uavsal_dw3x3_dot):
+        the tail of conv_out_st (model.py:333-334, 372-373).  Exact fp32 in every precision mode of the plan."""
+        c = a.c
+        self._meta(kind="dw", name=name, flops=2.0 * 10 * a.n * a.h * a.w * c, bytes=4.0 * a.n * a.h * a.w * (c + 1) + 4.0 * 12 * c,
+                   stride=1, dil=1, kernel="dw3x3_dot_kernel<4, 4>")
+        if self._dry:
+            return
+        key = ("dwdot", id(dwc), id(pl))
+        if key not in self._wcache:
+            s, b = P.fold_bn(dwbn)
+            s2, b2 = P.fold_bn(plbn)
+            self._wcache[key] = (self._dev(P.pack_dw_weight(dwc.weight)), self._dev(s), self._dev(b),
+                                 self._dev(pl.weight.detach().float().reshape(-1)), self._dev(s2.reshape(1)), self._dev(b2.reshape(1)))
+        w9, s, b, w2, s2, b2 = self._wcache[key]
+        d = L.DwDotDesc()
+        d.inp, d.ldi = a.ptr, a.ld
+        d.w9c, d.scale, d.bias, d.w2, d.scale2, d.bias2 = (t.data_ptr() for t in (w9, s, b, w2, s2, b2))
+        d.out, d.ldo = out.ptr, out.ld
+        d.n_img, d.H, d.W, d.C, d.act = a.n, a.h, a.w, c, act
+        self._add(self.lib.uavsal_plan_add_dw_dot, d, "plan_add_dw_dot(%s)" % name)
+
     def bilinear(self, name, a: V, out: V, src_mod=None, src_div=1):
         self._meta(kind="bilinear", name=name, flops=0.0, bytes=4.0 * out.n * out.h * out.w * out.c * 2)
         if self._dry:
@@ -651,6 +674,10 @@ class Engine:
             e = x
             dwc, dwbn, pl, plbn = seq[0][0], seq[0][1], seq[1], seq[2]
         ho, wo = (x.h - 1) // stride + 1, (x.w - 1) // stride + 1
+        if (DW_DOT and out.c == 1 and stride == 1 and dil == 1 and blk.expand_ratio != 1 and not blk.use_res_connect
+                and blk.hidden % 256 == 0 and blk.hidden <= 2048 and self.fuse_dw is not False):
+            self.dw_dot(name + ".dwpl", e, dwc, dwbn, pl, plbn, out, final_act)      # a dot product per pixel: bandwidth-bound
+            return
         if dil == 1 and blk.expand_ratio != 1 and (self.fuse_dw or (
                 self.fuse_dw is None and self._prec_for(name + ".dwpl") in ("f32", "f16x3") and stride == 1 and blk.hidden % 16 == 0
                 and x.n * x.h * x.w * blk.hidden >= FUSE_DW_MIN_WORK and _dwproj_patch_waste(x.h, x.w) <= FUSE_DW_MAX_WASTE)):

@@ -246,6 +246,26 @@ def dw3x3(x, weight, scale, bias, stride=1, dilation=1, act=L.ACT_RELU6, out=Non
     return sp if split_out else out
 
 
+def dw3x3_dot(x, weight, scale, bias, w2, scale2, bias2, act=L.ACT_NONE):
+    """Depthwise 3x3 (stride 1) + BN + ReLU6 -> 1x1 projection to ONE channel + BN + `act` in one launch (uavsal_dw3x3_dot).
+    `x` NHWC [n,h,w,C]; `weight` [C,1,3,3]; `w2` [1,C,1,1]; scale2 / bias2 one value each.  Returns [n,h,w,1]."""
+    lib = L.load()
+    ip, ldi, n, h, w, c = _nhwc_view(x)
+    dev = x.device
+    out = torch.empty((n, h, w, 1), dtype=torch.float32, device=dev)
+    keep = [P.pack_dw_weight(weight).to(dev), scale.float().contiguous().to(dev), bias.float().contiguous().to(dev),
+            w2.detach().float().reshape(-1).contiguous().to(dev), torch.as_tensor(scale2, dtype=torch.float32).reshape(1).to(dev),
+            torch.as_tensor(bias2, dtype=torch.float32).reshape(1).to(dev)]
+    d = L.DwDotDesc()
+    d.inp, d.ldi = ip, ldi
+    d.w9c, d.scale, d.bias, d.w2, d.scale2, d.bias2 = (t.data_ptr() for t in keep)
+    d.out, d.ldo = out.data_ptr(), 1
+    d.n_img, d.H, d.W, d.C, d.act = n, h, w, c, act
+    L.check(lib.uavsal_dw3x3_dot(C.byref(d), _stream(x)), "uavsal_dw3x3_dot")
+    torch.cuda.current_stream(dev).synchronize()
+    return out
+
+
 def fused_ir(x, w1, bn1, wd, bnd, w2, bn2, stride=1, residual=False, tile=0):
     """One inverted-residual block as a single launch (uavsal_fused_ir).  `x` NHWC; `w1` [hid,Cin,1,1] or None
     (no expand conv); `wd` [hid,1,3,3]; `w2` [Cout,hid,1,1]; bn* = (scale, bias) folded BatchNorms."""

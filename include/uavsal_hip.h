@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define UAVSAL_ABI_VERSION 16
+#define UAVSAL_ABI_VERSION 17
 
 /* argument errors */
 #define UAVSAL_EINVAL   (-1)  /* null pointer / non-positive size */
@@ -226,6 +226,25 @@ int uavsal_dw3x3(const uavsal_dw_desc* d, uavsal_stream_t stream);
 int uavsal_dw_variant(const uavsal_dw_desc* d);
 
 /*
+ * Depthwise 3x3 (stride 1, pad 1) + BN + ReLU6 followed by a 1x1 projection to ONE channel + BN + activation, one launch:
+ *   out[pixel] = act(scale2 * sum_c w2[c] * relu6(scale[c] * dw3x3(in)[pixel, c] + bias[c]) + bias2)
+ * Replaces the depthwise BasicConv2d + pw-linear conv + BN of dwBlock(256 -> 1) = conv_out_st and the final sigmoid
+ * (model.py:92-96, 333-334, 372-373): a dot product per pixel, bandwidth-bound on the expanded tensor.  Exact fp32
+ * whatever the GEMM precision of the plan; the summation order is a function of C only.
+ * C % 256 == 0, C <= 2048; w9c tap-major as in uavsal_dw_desc; scale2 / bias2 point at ONE value each (device memory).
+ * act: UAVSAL_ACT_NONE | UAVSAL_ACT_RELU6 | UAVSAL_ACT_SIGMOID.
+ */
+typedef struct uavsal_dw_dot_desc {
+    const float* in;   int32_t ldi;                              /* [n_img, H, W, C] NHWC, row pitch ldi floats */
+    const float* w9c;  const float* scale;  const float* bias;   /* depthwise taps [9][C], folded BN [C] */
+    const float* w2;   const float* scale2; const float* bias2;  /* projection weights [C]; folded BN of its one output */
+    float*       out;  int32_t ldo;                              /* [n_img * H * W] values, ldo floats apart */
+    int32_t n_img, H, W, C, act;
+} uavsal_dw_dot_desc;
+
+int uavsal_dw3x3_dot(const uavsal_dw_dot_desc* d, uavsal_stream_t stream);
+
+/*
  * Fused inverted-residual block: pw-expand + BN + ReLU6 -> depthwise 3x3 (stride 1 / 2, pad 1) + BN + ReLU6 ->
  * pw-linear + BN [+ x], ONE launch, the 6x-expanded tensors stay in LDS.  Replaces a whole torchvision
  * InvertedResidual / dwBlock (model.py:74-103, model_feature.py:62-66) where the block is bandwidth-bound:
@@ -406,6 +425,7 @@ uavsal_plan* uavsal_plan_create(void);
 void uavsal_plan_destroy(uavsal_plan* p);
 int uavsal_plan_add_conv(uavsal_plan* p, const uavsal_conv_desc* d);
 int uavsal_plan_add_dw(uavsal_plan* p, const uavsal_dw_desc* d);
+int uavsal_plan_add_dw_dot(uavsal_plan* p, const uavsal_dw_dot_desc* d);
 int uavsal_plan_add_stem(uavsal_plan* p, const uavsal_stem_desc* d);
 int uavsal_plan_add_bilinear(uavsal_plan* p, const uavsal_bilinear_desc* d);
 int uavsal_plan_add_tdiff(uavsal_plan* p, const uavsal_tdiff_desc* d);

@@ -592,6 +592,30 @@ def test_depthwise(ops, case):
     assert err <= 1e-5, (case, err)       # 9 fp32 fmas per output, order may differ
 
 
+@pytest.mark.parametrize("act", [0, 2])
+@pytest.mark.parametrize("case", [(2, 45, 80, 1536), (1, 7, 9, 256), (3, 13, 17, 512), (1, 4, 4, 2048), (1, 1, 1, 256)])
+def test_depthwise_dot_projection(ops, case, act):
+    """uavsal_dw3x3_dot: depthwise 3x3 + BN + ReLU6 -> 1x1 projection to ONE channel + BN + activation (the tail of conv_out_st,
+    reference model.py:92-96, 333-334, 372-373) against the three torch ops; deterministic (fixed summation order)."""
+    n, h, w, c = case
+    x = rnd((n, c, h, w), 161, 2.0)
+    wd = rnd((c, 1, 3, 3), 162, 0.4)
+    sd, bd = rnd((c,), 163) * 0.5 + 1.0, rnd((c,), 164)
+    w2 = rnd((1, c, 1, 1), 165, 2.0 / np.sqrt(c))
+    s2, b2 = 1.3, -0.2
+    d = torch.clamp(F.conv2d(x, wd, padding=1, groups=c) * sd.view(1, -1, 1, 1) + bd.view(1, -1, 1, 1), 0, 6)
+    ref = F.conv2d(d, w2) * s2 + b2
+    if act == 2:
+        ref = torch.sigmoid(ref)
+    got = ops.dw3x3_dot(nhwc(x), wd, sd, bd, w2, s2, b2, act=act)
+    again = ops.dw3x3_dot(nhwc(x), wd, sd, bd, w2, s2, b2, act=act)
+    assert torch.equal(got, again)
+    assert (nchw(got) - ref).abs().max().item() <= 3e-5, case
+    with pytest.raises(RuntimeError):
+        ops.dw3x3_dot(nhwc(rnd((1, 384, 5, 5), 166)), rnd((384, 1, 3, 3), 167), rnd((384,), 168), rnd((384,), 169),
+                      rnd((1, 384, 1, 1), 170), 1.0, 0.0)          # one workgroup = all channels of a patch: C % 256
+
+
 @pytest.mark.parametrize("size", [(2, 36, 64), (1, 45, 81), (2, 7, 9), (1, 21, 300), (2, 360, 640), (1, 1, 1), (1, 17, 129)])
 def test_stem(ops, size):
     """(the kernel works on 4 x 64 output tiles: several tiles per row, ragged last tiles, maps smaller than a tile)"""
