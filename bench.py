@@ -184,7 +184,7 @@ def kernel_rooflines(eng, prec, iters=5):
                 key = "dwproj_kernel<%d, %s, 0>" % (PREC_ID[prec], {256: "2, 4, 2, 2", 128: "2, 4, 2, 1", 64: "4, 2, 1, 1", 32: "4, 1, 1, 1"}[m["dwproj"]])
             elif m.get("fused_dw"):
                 key = "conv_gemm_kernel<%s, true>" % (H16_INST[m["tile"]] % (PREC_ID[prec], 1))
-        elif m["kind"] in ("dw", "fused_ir"):
+        elif m["kind"] in ("dw", "dw_dot", "fused_ir"):
             key = m["kernel"]                  # uavsal_dw_variant / the fused block instance the library launches
         else:
             key = m["kind"]
@@ -525,6 +525,14 @@ def main():
                 if big in fam["instances"]:
                     fam["instances"][big]["traffic"], _ = measured_traffic(big, C, T, H, W, args.prec)
                 result["roofline_dw"] = fam
+            dots = {k: g for k, g in groups.items() if g["kind"] == "dw_dot"}
+            for k, g in dots.items():
+                # the decoder's depthwise 3x3 + one-channel projection launch: a depthwise conv whose output is a dot product per pixel
+                # (bytes: the expanded tensor once + one float per pixel); reported by itself, NOT inside the stand-alone family above
+                # (whose members write C channels per pixel and are comparable with the earlier rounds)
+                result["roofline_dw_dot"] = roofline_obj(k, g, args.prec)
+                result["roofline_dw_dot"]["share_of_kernel_time"] = round(g["ms"] / tot, 3)
+                result["roofline_dw_dot"]["traffic"], _ = measured_traffic(k, C, T, H, W, args.prec)
             fus = fused_family(groups)
             if fus:
                 fus["share_of_kernel_time"] = round(fus["kernel_ms_per_step"] / tot, 3)

@@ -553,7 +553,7 @@ class Engine:
         """Depthwise 3x3 + BN + ReLU6 -> projection to ONE channel + BN + act as one bandwidth-bound launch (uavsal_dw3x3_dot):
         the tail of conv_out_st (model.py:333-334, 372-373).  Exact fp32 in every precision mode of the plan."""
         c = a.c
-        self._meta(kind="dw", name=name, flops=2.0 * 10 * a.n * a.h * a.w * c, bytes=4.0 * a.n * a.h * a.w * (c + 1) + 4.0 * 12 * c,
+        self._meta(kind="dw_dot", name=name, flops=2.0 * 10 * a.n * a.h * a.w * c, bytes=4.0 * a.n * a.h * a.w * (c + 1) + 4.0 * 12 * c,
                    stride=1, dil=1, kernel="dw3x3_dot_kernel<4, 4>")
         if self._dry:
             return

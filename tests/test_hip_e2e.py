@@ -192,7 +192,7 @@ def test_default_fp32_plan_composition(hip_model):
     for nm in ("st0.sub", "st1.sub", "gauss.1", "ob.1", "st0.sp", "fust", "fucbst"):
         assert nm + ".dwpl" in meta and meta[nm + ".dwpl"]["dwproj"] != 0, nm
     # the decoder's 1536 -> 1 projection: a dot product per pixel inside the depthwise launch, not a GEMM + reduce launch
-    assert meta["conv_out_st.dwpl"]["kind"] == "dw" and meta["conv_out_st.dwpl"]["kernel"].startswith("dw3x3_dot_kernel")
+    assert meta["conv_out_st.dwpl"]["kind"] == "dw_dot" and meta["conv_out_st.dwpl"]["kernel"].startswith("dw3x3_dot_kernel")
     for i in range(1, 8):
         assert meta["features.%d" % i]["kind"] == "fused_ir" and meta["features.%d" % i]["kernel"].startswith("fused_ir_kernel")
     # round 4: the stride-1 blocks of the 23x40 map (features.8-13: 240 workgroups of the mid-channel kernel) are one launch each

@@ -5,7 +5,8 @@
 set -e
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r4final
-rm -rf $O && mkdir -p $O
+if [ -z "$ONLY_BENCH" ]; then rm -rf $O; fi      # ONLY_BENCH=1: just the bench lines again (bench.py changed, kernels did not)
+mkdir -p $O
 run_set() {   # $1 = prec, $2 = clips, $3 = label, $4 = file tag (bench.py _wl_tag), $5... = extra bench arguments
   local P=$1 C=$2 L="$3" T=$4; shift 4
   cd /tmp && export TMPDIR=/tmp
@@ -20,10 +21,12 @@ run_set() {   # $1 = prec, $2 = clips, $3 = label, $4 = file tag (bench.py _wl_t
   cp $O/r4_hbm_traffic_$T.json $O/r4_kernel_stats_$T.json profiles/     # so that the bench line below can quote them
   rm -rf $O/f_$T $O/w_$T $O/kt_$T/kt_kernel_trace.csv
 }
+if [ -z "$ONLY_BENCH" ]; then
 run_set f32 1 "bench.py (configs[1]: 360x640, 1 clip x 8 frames, f32)" f32_c1
 run_set f32 8 "bench.py --clips 8 (one GPU's share of configs[3]: 360x640, 8 clips x 8 frames, f32)" f32_c8
 run_set f16x3 8 "bench.py --prec f16x3 --clips 8 (configs[2]: 360x640, 8 clips x 8 frames, split-fp16 MFMA)" f16x3_c8
 run_set f32 4 "bench.py --height 720 --width 1280 --frames 16 --clips 4 --persistent-state 1 (configs[4])" f32_c4_720x1280_t16 --height 720 --width 1280 --frames 16 --persistent-state 1 --steps 5 --warmup 2
+fi
 cd $R
 python3 bench.py > $O/r4_bench_default.json 2> $O/r4_bench_default.err
 python3 bench.py --clips 8 --no-extra --no-cpu-baseline > $O/r4_bench_f32_c8.json 2> $O/r4_bench_f32_c8.err
