@@ -52,7 +52,7 @@ class DwDesc(C.Structure):
                 ("out", _f), ("ldo", C.c_int32),
                 ("n_img", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32),
                 ("stride", C.c_int32), ("dilation", C.c_int32), ("act", C.c_int32),
-                ("out_split", _f), ("ldos", C.c_int32)]
+                ("out_split", _f), ("ldos", C.c_int32), ("dil_group_c", C.c_int32), ("dil_groups", C.c_int32 * 4)]
 
 
 class DwDotDesc(C.Structure):
@@ -198,7 +198,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.uavsal_abi_version() != 17:
+    if lib.uavsal_abi_version() != 18:
         raise RuntimeError("libuavsal_hip.so ABI version mismatch")
     for i, t in enumerate(DESC_TYPES):
         if lib.uavsal_sizeof_desc(i) != C.sizeof(t):

@@ -30,6 +30,7 @@ struct DwK {
     int tiles_x, tiles_y, n_img;
     long long total;   // work items = n_img * tiles_y * tiles_x * C4
     int nblk;
+    int dgc, dils[4];  // dgc > 0: channel c has dilation dils[c / dgc] (several dilated branches of one map in one launch)
 };
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -121,14 +122,15 @@ __global__ __launch_bounds__(256) void dw3x3_dilated_kernel(const DwK p) {
     const int n = (int)(t / p.Ho);
     const int c = c4 * 4;
     const float* inb = p.in + (size_t)n * p.H * p.W * p.ldi + c;
+    const int dil = p.dgc ? p.dils[c / p.dgc] : p.dil;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
-        const int iy = oy + (ky - 1) * p.dil;
+        const int iy = oy + (ky - 1) * dil;
         if (iy < 0 || iy >= p.H) continue;
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-            const int ix = ox + (kx - 1) * p.dil;
+            const int ix = ox + (kx - 1) * dil;
             if (ix < 0 || ix >= p.W) continue;
             acc += ld4(inb + ((size_t)iy * p.W + ix) * p.ldi) * ld4(p.w9c + (size_t)(ky * 3 + kx) * (p.C4 * 4) + c);
         }
@@ -171,6 +173,7 @@ __global__ __launch_bounds__(256) void dw3x3_map_lds_kernel(const DwK p) {
     const f32x4 sc = ld4(p.scale + cc), bi = ld4(p.bias + cc);
     __syncthreads();
     if (!cok) return;
+    const int dil = p.dgc ? p.dils[c0 / p.dgc] : p.dil;          // (a slab never straddles two groups: dgc % CB == 0)
     float* outb = p.out + (size_t)n * HW * p.ldo + c;
     for (int i = threadIdx.x; i < HW * Q; i += 256) {
         const int pix = i / Q;
@@ -178,11 +181,11 @@ __global__ __launch_bounds__(256) void dw3x3_map_lds_kernel(const DwK p) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
-            const int iy = oy + (ky - 1) * p.dil;
+            const int iy = oy + (ky - 1) * dil;
             if (iy < 0 || iy >= p.H) continue;
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
-                const int ix = ox + (kx - 1) * p.dil;
+                const int ix = ox + (kx - 1) * dil;
                 if (ix < 0 || ix >= p.W) continue;
                 acc += sm[(iy * p.W + ix) * Q + q] * wt[ky * 3 + kx];
             }
@@ -224,6 +227,10 @@ static inline int map_lds_slab(const DwK& k) {
 // which kernel a descriptor gets: 1 = dw3x3_kernel<1,4,4>, 2 = <1,2,2>, 3 = <2,2,2>, 4 = dw3x3_dilated_kernel,
 // 16 / 32 / 64 = dw3x3_map_lds_kernel<CB>
 static int dw_variant(const DwK& k, int stride, int dilation) {
+    if (k.dgc) {              // several dilated branches in one launch: the whole-map kernel (each byte fetched once whatever the dilation)
+        const int cb = map_lds_slab(k);
+        return (cb && k.dgc % cb == 0) ? cb : 4;
+    }
     // Measured at 8 x 12x20 x 1920 (profiles/r2_dw_small_maps.md): the whole-map LDS kernel wins only while most
     // taps fall inside the map (d=6: 10.9 vs 15.1 us); d=12/18 (centre row only) and dilation 1 (2x2 patches
     // already fetch every input 2.25x, from L1/L2) are faster on the direct kernels (8.7 / 7.7 us vs 9.3 / 9.4;
@@ -368,6 +375,15 @@ extern "C" int uavsal_dw3x3(const uavsal_dw_desc* d, uavsal_stream_t stream) {
     k.Ho = (d->H - 1) / d->stride + 1; k.Wo = (d->W - 1) / d->stride + 1;
     k.C4 = d->C / 4; k.dil = d->dilation; k.act = d->act; k.n_img = d->n_img;
     k.tiles_x = k.tiles_y = 0; k.total = 0; k.nblk = 0;
+    k.dgc = 0; k.dils[0] = k.dils[1] = k.dils[2] = k.dils[3] = d->dilation;
+    if (d->dil_group_c) {
+        if (d->dil_group_c < 0 || (d->dil_group_c & 3) || d->stride != 1 || d->out_split || d->C > 4 * d->dil_group_c) return UAVSAL_ESHAPE;
+        for (int i = 0; i < 4; ++i) {
+            if ((long long)i * d->dil_group_c < d->C && d->dil_groups[i] < 1) return UAVSAL_ESHAPE;
+            k.dils[i] = d->dil_groups[i] > 0 ? d->dil_groups[i] : 1;
+        }
+        k.dgc = d->dil_group_c;
+    }
     hipStream_t s = (hipStream_t)stream;
     const int v = dw_variant(k, d->stride, d->dilation);
     switch (v) {
@@ -393,7 +409,7 @@ extern "C" int uavsal_dw_variant(const uavsal_dw_desc* d) {
     if ((d->stride != 1 && d->stride != 2) || d->dilation < 1 || (d->stride == 2 && d->dilation != 1)) return UAVSAL_ESHAPE;
     DwK k;
     k.H = d->H; k.W = d->W; k.Ho = (d->H - 1) / d->stride + 1; k.Wo = (d->W - 1) / d->stride + 1;
-    k.C4 = d->C / 4; k.n_img = d->n_img;
+    k.C4 = d->C / 4; k.n_img = d->n_img; k.dgc = d->dil_group_c > 0 ? d->dil_group_c : 0;
     return dw_variant(k, d->stride, d->dilation);
 }
 

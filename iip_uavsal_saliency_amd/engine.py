@@ -76,6 +76,7 @@ MID_MIN_WGS = int(os.environ.get("UAVSAL_MID_MIN_WGS", "1"))
 MID_MAX_WGS = int(os.environ.get("UAVSAL_MID_MAX_WGS", "288"))
 
 
+ASPP_DW_MERGE = os.environ.get("UAVSAL_ASPP_DW_MERGE", "1") == "1"      # 0: the three dilated ASPP depthwise convs as three launches on three lanes
 DW_DOT = os.environ.get("UAVSAL_DW_DOT", "1") == "1"       # 0: the one-channel projection of conv_out_st as a dwproj GEMM + reduce launch
 _TILE_OVERRIDE = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in os.environ.get("UAVSAL_TILE_OVERRIDE", "").split(",") if "=" in kv}
 
@@ -526,16 +527,27 @@ class Engine:
         c = a.c
         ho, wo = (a.h - 1) // stride + 1, (a.w - 1) // stride + 1
         byts = 4.0 * a.n * c * (a.h * a.w + ho * wo) + 4.0 * 9 * c + 4.0 * 2 * c
-        self._meta(kind="dw", name=name, flops=2.0 * 9 * a.n * ho * wo * c, bytes=byts, stride=stride, dil=dilation,
-                   patches44=a.n * ((ho + 3) // 4) * ((wo + 3) // 4) * (c // 4))
+        self._meta(kind="dw", name=name, flops=2.0 * 9 * a.n * ho * wo * c, bytes=byts, stride=stride,
+                   dil=dilation if not isinstance(dilation, (list, tuple)) else tuple(dilation), patches44=a.n * ((ho + 3) // 4) * ((wo + 3) // 4) * (c // 4))
         if self._dry:
             return
-        key = ("dw", id(conv))
+        grouped = isinstance(conv, (list, tuple))      # several dilated branches of one map: channel groups with their own dilation
+        key = ("dw",) + tuple(id(c_) for c_ in conv) if grouped else ("dw", id(conv))
         if key not in self._wcache:
-            s, b = P.fold_bn(bn)
-            self._wcache[key] = (self._dev(P.pack_dw_weight(conv.weight)), self._dev(s), self._dev(b))
+            if grouped:
+                parts = [P.fold_bn(b_) for b_ in bn]
+                self._wcache[key] = (self._dev(torch.cat([P.pack_dw_weight(c_.weight) for c_ in conv], 1)),
+                                     self._dev(torch.cat([p_[0] for p_ in parts])), self._dev(torch.cat([p_[1] for p_ in parts])))
+            else:
+                s, b = P.fold_bn(bn)
+                self._wcache[key] = (self._dev(P.pack_dw_weight(conv.weight)), self._dev(s), self._dev(b))
         w9, s, b = self._wcache[key]
         d = L.DwDesc()
+        if grouped:
+            d.dil_group_c = c // len(conv)
+            for gi, dl in enumerate(dilation):
+                d.dil_groups[gi] = dl
+            dilation = dilation[0]
         d.inp, d.ldi = a.ptr, a.ld
         d.w9c, d.scale, d.bias = w9.data_ptr(), s.data_ptr(), b.data_ptr()
         if out.t is None:            # the projection GEMM stages this tensor pre-split: no fp32 copy
@@ -816,6 +828,7 @@ class Engine:
         aspp_lanes = int(os.environ.get("UAVSAL_ASPP_LANES", "1"))
         fork = self.fork if aspp_lanes else (lambda lane: None)
         join = self.join if aspp_lanes else (lambda lane: None)
+        aspp_dw_merged = False
         if int(os.environ.get("UAVSAL_ASPP_MERGE", "1")) and all(b.expand_ratio != 1 for b in branches):
             # the three dilated branches expand the SAME map with the same shape: one GEMM with their output channels
             # side by side (320 -> 3 x 1920: 675 tiles instead of three launches of 225 fighting for the chip on three
@@ -827,11 +840,19 @@ class Engine:
                 # ... and their three projections (1920 -> 256 each, different inputs) are ONE launch too: output-channel
                 # groups with their own A columns (uavsal_conv_desc.n_group), K shared out over workgroups
                 d3 = self._scr("D3", N, c5.h, c5.w, 3 * hid)
-                for bi, b in enumerate(branches):
-                    fork(3 + bi)
-                    self.dw("aspp%d.dw" % (bi + 2), e3.slice(bi * hid, hid), b.conv[1][0], b.conv[1][1], d3.slice(bi * hid, hid),
-                            b.stride, getattr(b, "dilation", 1))
-                    self.main()
+                if ASPP_DW_MERGE and all(b.stride == 1 for b in branches) and hid % 64 == 0:
+                    # ... and so are their three dilated depthwise convs: channel groups with their own dilation in the whole-map
+                    # kernel (uavsal_dw_desc.dil_group_c).  Three launches on three lanes cost six event operations on the main
+                    # stream (~25 us between aspp.pw and aspp.pl) for ~10 us of overlap
+                    self.dw("aspp.dw", e3, [b.conv[1][0] for b in branches], [b.conv[1][1] for b in branches], d3, 1,
+                            [getattr(b, "dilation", 1) for b in branches])
+                    aspp_dw_merged = True
+                else:
+                    for bi, b in enumerate(branches):
+                        fork(3 + bi)
+                        self.dw("aspp%d.dw" % (bi + 2), e3.slice(bi * hid, hid), b.conv[1][0], b.conv[1][1], d3.slice(bi * hid, hid),
+                                b.stride, getattr(b, "dilation", 1))
+                        self.main()
                 aspp_grouped = d3
             else:
                 aspp_grouped = None
@@ -851,9 +872,10 @@ class Engine:
         self.conv("conv_lv3", c3, sf.conv_lv3[0], sf.conv_lv3[1], cat.slice(384, 64), R6)
         self.main()
         self.conv("aspp1", c5, sf.lv5_aspp1[0], sf.lv5_aspp1[1], aspp.slice(0, 256), R6)
-        join(3)
-        join(4)
-        join(5)
+        if not aspp_dw_merged:
+            join(3)
+            join(4)
+            join(5)
         if aspp_grouped is not None:
             hid = branches[0].hidden
             self.conv("aspp.pl", aspp_grouped.slice(0, hid), [b.conv[2] for b in branches], [b.conv[3] for b in branches],

@@ -221,8 +221,9 @@ def twa_step(x_t, h_prev, pre_t, w_h, prec="f32", tile=0, stream_k=False):
     return out
 
 
-def dw3x3(x, weight, scale, bias, stride=1, dilation=1, act=L.ACT_RELU6, out=None, split_out=False):
-    """`split_out`: the result is written as a split shadow (fp16 `[n,h,w,C/32,2,32]`) instead of fp32."""
+def dw3x3(x, weight, scale, bias, stride=1, dilation=1, act=L.ACT_RELU6, out=None, split_out=False, dil_groups=None):
+    """`split_out`: the result is written as a split shadow (fp16 `[n,h,w,C/32,2,32]`) instead of fp32.
+    `dil_groups`: a list of dilations, one per equal channel group (uavsal_dw_desc.dil_group_c)."""
     lib = L.load()
     ip, ldi, n, h, w, c = _nhwc_view(x)
     ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
@@ -241,6 +242,10 @@ def dw3x3(x, weight, scale, bias, stride=1, dilation=1, act=L.ACT_RELU6, out=Non
     d.n_img, d.H, d.W, d.C, d.stride, d.dilation, d.act = n, h, w, c, stride, dilation, act
     if split_out:
         d.out_split, d.ldos = sp.data_ptr(), 2 * c
+    if dil_groups:
+        d.dil_group_c = c // len(dil_groups)
+        for i, dl in enumerate(dil_groups):
+            d.dil_groups[i] = dl
     L.check(lib.uavsal_dw3x3(C.byref(d), _stream(x)), "uavsal_dw3x3")
     torch.cuda.current_stream(x.device).synchronize()
     return sp if split_out else out

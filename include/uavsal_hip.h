@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define UAVSAL_ABI_VERSION 17
+#define UAVSAL_ABI_VERSION 18
 
 /* argument errors */
 #define UAVSAL_EINVAL   (-1)  /* null pointer / non-positive size */
@@ -217,6 +217,10 @@ typedef struct uavsal_dw_desc {
     /* optional: write the result as a split shadow (see uavsal_conv_desc) INSTEAD of fp32 -- the only consumer
      * of a depthwise output is the projection GEMM (model.py:94).  `out` may then be NULL.  dilation 1 only. */
     void* out_split;  int32_t ldos;
+    /* optional: several dilated branches of the SAME map in one launch (the three dilated ASPP depthwise convs, model.py:125-127,
+     * on the channel slices of their merged expand): dil_group_c > 0 (a multiple of 4, C <= 4 * dil_group_c) gives channel c the
+     * dilation dil_groups[c / dil_group_c]; `dilation` is then ignored.  Stride 1, no split output. */
+    int32_t dil_group_c;  int32_t dil_groups[4];
 } uavsal_dw_desc;
 
 int uavsal_dw3x3(const uavsal_dw_desc* d, uavsal_stream_t stream);

@@ -189,6 +189,7 @@ def test_default_fp32_plan_composition(hip_model):
         assert nm + ".xin" in meta and nm + ".xout" in meta and meta[nm]["tile"] == 8, nm
     assert "aspp.pl" in meta and meta["aspp.pl"]["tile"] == 11 and meta["aspp.pl"]["Nc"] == 768 and meta["aspp.pl"]["K"] == 1920
     assert not any(n in meta for n in ("aspp2.pl", "aspp3.pl", "aspp4.pl"))
+    assert "aspp.dw" in meta and meta["aspp.dw"]["dil"] == (6, 12, 18) and not any(n in meta for n in ("aspp2.dw", "aspp3.dw", "aspp4.dw"))
     for nm in ("st0.sub", "st1.sub", "gauss.1", "ob.1", "st0.sp", "fust", "fucbst"):
         assert nm + ".dwpl" in meta and meta[nm + ".dwpl"]["dwproj"] != 0, nm
     # the decoder's 1536 -> 1 projection: a dot product per pixel inside the depthwise launch, not a GEMM + reduce launch

@@ -592,6 +592,24 @@ def test_depthwise(ops, case):
     assert err <= 1e-5, (case, err)       # 9 fp32 fmas per output, order may differ
 
 
+@pytest.mark.parametrize("case", [(8, 12, 20, 3 * 1920, (6, 12, 18)), (2, 9, 13, 192, (2, 3, 5)), (1, 45, 80, 128, (1, 4)), (2, 130, 140, 96, (3, 7, 1))])
+def test_depthwise_channel_groups_with_their_own_dilation(ops, case):
+    """uavsal_dw_desc.dil_group_c: the dilated branches of one map in one launch (the three ASPP depthwise convs on the slices of
+    their merged expand, model.py:125-127, 142-147) == one torch depthwise conv per group.  Whole-map LDS kernel where the map
+    fits, the per-pixel kernel otherwise (130x140)."""
+    n, h, w, c, dils = case
+    x = rnd((n, c, h, w), 171, 2.0)
+    wd = rnd((c, 1, 3, 3), 172, 0.4)
+    sd, bd = rnd((c,), 173) * 0.5 + 1.0, rnd((c,), 174)
+    g = c // len(dils)
+    ref = torch.cat([F.conv2d(x[:, i * g:(i + 1) * g], wd[i * g:(i + 1) * g], padding=d, dilation=d, groups=g) for i, d in enumerate(dils)], 1)
+    ref = torch.clamp(ref * sd.view(1, -1, 1, 1) + bd.view(1, -1, 1, 1), 0, 6)
+    got = ops.dw3x3(nhwc(x), wd, sd, bd, dil_groups=list(dils))
+    assert (nchw(got) - ref).abs().max().item() <= 2e-5, case
+    with pytest.raises(RuntimeError):
+        ops.dw3x3(nhwc(x), wd, sd, bd, stride=2, dil_groups=list(dils))
+
+
 @pytest.mark.parametrize("act", [0, 2])
 @pytest.mark.parametrize("case", [(2, 45, 80, 1536), (1, 7, 9, 256), (3, 13, 17, 512), (1, 4, 4, 2048), (1, 1, 1, 256)])
 def test_depthwise_dot_projection(ops, case, act):

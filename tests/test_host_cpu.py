@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert declared == bound, (declared ^ bound)
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.uavsal_abi_version() == 17
+    assert lib.uavsal_abi_version() == 18
     assert b"gfx950" in lib.uavsal_build_info()
 
 
