@@ -76,6 +76,7 @@ MID_MIN_WGS = int(os.environ.get("UAVSAL_MID_MIN_WGS", "1"))
 MID_MAX_WGS = int(os.environ.get("UAVSAL_MID_MAX_WGS", "288"))
 
 
+PRIORS_OB_LANE = int(os.environ.get("UAVSAL_PRIORS_OB_LANE", "2"))      # 1: both prior nets on lane 1 (two event operations fewer)
 ASPP_DW_MERGE = os.environ.get("UAVSAL_ASPP_DW_MERGE", "1") == "1"      # 0: the three dilated ASPP depthwise convs as three launches on three lanes
 DW_DOT = os.environ.get("UAVSAL_DW_DOT", "1") == "1"       # 0: the one-channel projection of conv_out_st as a dwproj GEMM + reduce launch
 _TILE_OVERRIDE = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in os.environ.get("UAVSAL_TILE_OVERRIDE", "").split(",") if "=" in kv}
@@ -792,8 +793,12 @@ class Engine:
                 self._no_shadow.add("cb_static")
                 for lane, nm, src, dst, c, blocks, mid, sl in (
                         (1, "gauss", "cb0_in", g0, 8, m.gauss_cb_layer, g1, 0),
-                        (2, "ob", "cb1_in", o0, 20, m.ob_cb_layer, o1, 64)):
-                    self.fork(lane)
+                        (PRIORS_OB_LANE, "ob", "cb1_in", o0, 20, m.ob_cb_layer, o1, 64)):
+                    if lane != 1 or nm == "gauss":       # (both nets on lane 1: one fork / join pair)
+                        self.fork(lane)
+                    else:
+                        L.check(self.lib.uavsal_plan_set_lane(self.plan, lane), "plan_set_lane") if not self._dry else None
+                        self._lane = lane
                     if self._dry:
                         self._meta(kind="layout", name=nm + ".in", flops=0.0, bytes=8.0 * Np * c * hw)
                     else:
@@ -950,7 +955,8 @@ class Engine:
         else:                            # independent clips: frame (c,t) <- clip c
             self.bilinear("ctx.up", cx2, cb.slice(128, 64), src_mod=N, src_div=self.ctx_T)
         self.join(1)
-        self.join(2)
+        if PRIORS_OB_LANE != 1:
+            self.join(2)
         self.ir_block("fucb", cb, m.fucb_layer[0], fu.slice(256, 64))
         self.named["fust_in_cb"] = fu.slice(256, 64)
         xf = self._buf("prefuse", N, h, w, 256)
