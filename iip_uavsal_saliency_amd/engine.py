@@ -76,7 +76,7 @@ MID_MIN_WGS = int(os.environ.get("UAVSAL_MID_MIN_WGS", "1"))
 MID_MAX_WGS = int(os.environ.get("UAVSAL_MID_MAX_WGS", "288"))
 
 
-PRIORS_OB_LANE = int(os.environ.get("UAVSAL_PRIORS_OB_LANE", "2"))      # 1: both prior nets on lane 1 (two event operations fewer)
+PRIORS_OB_LANE = int(os.environ.get("UAVSAL_PRIORS_OB_LANE", "1"))      # 1: both prior nets on lane 1 (two event operations fewer on the main stream: 4.29 -> 4.26 ms at one clip); 2: a lane each
 ASPP_DW_MERGE = os.environ.get("UAVSAL_ASPP_DW_MERGE", "1") == "1"      # 0: the three dilated ASPP depthwise convs as three launches on three lanes
 DW_DOT = os.environ.get("UAVSAL_DW_DOT", "1") == "1"       # 0: the one-channel projection of conv_out_st as a dwproj GEMM + reduce launch
 _TILE_OVERRIDE = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in os.environ.get("UAVSAL_TILE_OVERRIDE", "").split(",") if "=" in kv}
@@ -776,10 +776,13 @@ class Engine:
             self._add(self.lib.uavsal_plan_add_stem, d, "plan_add_stem")
         tapsrc = {}
         cb = g1 = o1 = None
-        priors_at = int(os.environ.get("UAVSAL_PRIORS_AT", "5"))
+        # where the prior nets' side lane forks off: beside features.11-17 while those launches are latency-bound (one round of the
+        # chip each: up to two clips of 8 frames; 4.26 -> 4.25 ms at one clip), beside features.5-10 from there on (8 clips: 27.92
+        # vs 27.97 ms).  A function of the frame count only
+        priors_at = int(os.environ.get("UAVSAL_PRIORS_AT", "11" if N <= 16 else "5"))
         for i in range(1, 18):
             if i == priors_at:
-                self._mark("backbone.0-4", s0)
+                self._mark("backbone.0-%d" % (priors_at - 1), s0)
                 # ---- gaussian / observed prior nets (model.py:349,352): they depend only on the caller's
                 #      priors and are needed at fucb_layer, so they run on lanes 1 and 2 beside the backbone.
                 #      Recorded HERE, not at the top of the plan: the host launches in recording order, and
@@ -818,7 +821,7 @@ class Engine:
             tapsrc[i] = y
         c3, c4, c5 = tapsrc[6], tapsrc[13], tapsrc[17]
         self.named.update(c3=c3, c4=c4, c5=c5)
-        self._mark("backbone.5-17", s0)
+        self._mark("backbone.%d-17" % priors_at, s0)
 
         # ---- SRF-Net head (model.py:139-158)
         s0 = len(self.ops_meta)
