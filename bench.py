@@ -177,7 +177,9 @@ def kernel_rooflines(eng, prec, iters=5):
     """Per-op device time (hipEvents on the launch stream) grouped by kernel instance."""
     groups = {}
     for i, m in enumerate(eng.ops_meta):
-        ms = eng.time_ops(i, i + 1, iters)
+        # two measurements, the smaller one: a one-off stall of the box (tens of ms, seen a few times per hour on this pool) inside
+        # a 5-launch average would otherwise own the whole family figure
+        ms = min(eng.time_ops(i, i + 1, iters), eng.time_ops(i, i + 1, iters))
         if m["kind"].startswith("conv"):
             key = kernel_symbol(prec, m["tile"], 9 if m["kind"] == "conv3" else 1, m.get("streamk", 0), m.get("split", False))
             if m.get("dwproj"):
