@@ -453,3 +453,23 @@ def test_bench_gpus_2_on_a_box_without_two_gpus_exits_nonzero():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and r.stdout.strip() == ""
+
+
+def test_committed_bench_line_carries_the_contract_fields():
+    """The bench line the round's last collection produced (profiles/r4_bench_default.json, written by `python bench.py` on the
+    MI355X): every field of the driver's contract, the roofline and cpu_baseline objects, and a stamp-matched PMC traffic figure."""
+    import json
+    r = json.load(open(os.path.join(ROOT, "profiles", "r4_bench_default.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "parity", "ranks_seen", "scaling_reference"):
+        assert k in r, k
+    assert r["n_gpus"] == 1 and r["higher_is_better"] is True and r["scaling"] == "weak" and r["vs_baseline"] is None
+    assert r["dtype"] == "f32" and r["data"] == "synthetic" and "workload" in r["config"] and "model" not in r["config"]
+    assert abs(r["value"] - 8 * r["steps"] / (r["ms_per_step"] * 1e-3 * r["steps"])) < 1.0          # frames / time of the median window
+    ro = r["roofline"]
+    assert ro["bound"] in ("hbm", "mfma") and ro["unit"] in ("GB/s", "TFLOP/s") and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-3
+    assert ro["traffic"] is not None and ro["in_loop"]["status"] == "ok"
+    cb = r["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb and cb["unit"] == "frames/s"
+    assert r["parity"]["max_abs_map_vs_cpu_ref"] <= r["parity"]["tolerance"] == 1e-3
+    assert r["scaling_reference"]["roofline_dw"]["frac"] >= 0.60          # north_star: >= 60 % of the HBM roofline on the depthwise convs
