@@ -739,8 +739,17 @@ class Engine:
         lstm_model = getattr(m, "rnn_type", "twa") == "lstm"
         c0 = self._buf("c0", self.n_seq, h, w, 256) if lstm_model else None
         Np = 1 if self.static_priors else N
-        g0 = self._buf("gauss_in", Np, h, w, 8)
-        o0 = self._buf("ob_in", Np, h, w, 20)
+        # which priors this model has (reference model.py:281-324: a disabled prior has no net, and with none at all the two
+        # fusion blocks do not exist either); enabled priors keep the reference's concat order gauss | observed | context
+        use_g, use_o, use_c = (bool(getattr(m, a, 1)) for a in ("use_gauss_prior", "use_ob_prior", "use_context_prior"))
+        num_cb = int(use_g) + int(use_o) + int(use_c)
+        cb_off = {}
+        for nm_, on_ in (("gauss", use_g), ("ob", use_o), ("ctx", use_c)):
+            if on_:
+                cb_off[nm_] = 64 * len(cb_off)
+        self.use_priors = (use_g, use_o, use_c)
+        g0 = self._buf("gauss_in", Np, h, w, 8) if use_g else None
+        o0 = self._buf("ob_in", Np, h, w, 20) if use_o else None
         if not self.persistent:          # persistent mode: h0 / c0 ARE the state, staged only on demand (run())
             names = ["state.in"] + (["cstate.in"] if lstm_model else [])
             for nm, src, dst in zip(names, ("state_in", "cstate_in"), (h0, c0)):
@@ -775,7 +784,7 @@ class Engine:
                 d.mean[i], d.stdv[i] = synth.IMAGENET_MEAN[i], synth.IMAGENET_STD[i]
             self._add(self.lib.uavsal_plan_add_stem, d, "plan_add_stem")
         tapsrc = {}
-        cb = g1 = o1 = None
+        cb = None
         # where the prior nets' side lane forks off: beside features.11-17 while those launches are latency-bound (one round of the
         # chip each: up to two clips of 8 frames; 4.26 -> 4.25 ms at one clip), beside features.5-10 from there on (8 clips: 27.92
         # vs 27.97 ms).  A function of the frame count only
@@ -789,16 +798,21 @@ class Engine:
                 #      with these 14 small launches (+ 4 event operations) in front of it the stem reached
                 #      the GPU ~100 us late on every call (rocprofv3 kernel trace, profiles/r2_step_timeline.md).
                 s0 = len(self.ops_meta)
-                cb = self._buf("cb192", N, h, w, 192)
-                g1 = self._buf("gauss1", Np, h, w, 64)
-                o1 = self._buf("ob1", Np, h, w, 64)
+                cb = self._buf("cb192", N, h, w, 64 * num_cb) if num_cb else None
                 cbs = self._buf("cb_static", 1, h, w, 128) if self.static_priors else cb
                 self._no_shadow.add("cb_static")
-                for lane, nm, src, dst, c, blocks, mid, sl in (
-                        (1, "gauss", "cb0_in", g0, 8, m.gauss_cb_layer, g1, 0),
-                        (PRIORS_OB_LANE, "ob", "cb1_in", o0, 20, m.ob_cb_layer, o1, 64)):
-                    if lane != 1 or nm == "gauss":       # (both nets on lane 1: one fork / join pair)
+                forked = set()
+                for lane, nm, src, dst, c, on in (
+                        (1, "gauss", "cb0_in", g0, 8, use_g),
+                        (PRIORS_OB_LANE, "ob", "cb1_in", o0, 20, use_o)):
+                    if not on:
+                        continue
+                    blocks = m.gauss_cb_layer if nm == "gauss" else m.ob_cb_layer
+                    mid = self._buf(nm + "1", Np, h, w, 64)
+                    sl = cb_off[nm]
+                    if lane not in forked:               # (both nets on lane 1: one fork / join pair)
                         self.fork(lane)
+                        forked.add(lane)
                     else:
                         L.check(self.lib.uavsal_plan_set_lane(self.plan, lane), "plan_set_lane") if not self._dry else None
                         self._lane = lane
@@ -811,6 +825,7 @@ class Engine:
                     if self.static_priors:      # frame 0 of the net's output -> every frame (same-size resize: an exact copy)
                         self.bilinear(nm + ".bcast", cbs.slice(sl, 64), cb.slice(sl, 64), src_mod=1)
                     self.main()
+                self._prior_lanes = sorted(forked)
                 self._mark("priors_side", s0)
                 s0 = len(self.ops_meta)
             blk = feats[i]
@@ -936,34 +951,39 @@ class Engine:
 
         # ---- fuse + multi-prior net (model.py:344-365)
         s0 = len(self.ops_meta)
-        fu = self._buf("fu320", N, h, w, 320)
-        xs = fu.slice(0, 256)
-        self.ir_block("fust", x, m.fust_layer[0], xs)
-        B = N // self.ctx_T
-        tsum = self._buf("ctx_sum", B, h, w, 256)
-        self._meta(kind="tsum", name="ctx.sum", flops=0.0, bytes=4.0 * (N + B) * hw * 256)
-        if not self._dry:
-            d = L.TsumDesc()
-            d.inp, d.ldi, d.out, d.ldo = xs.ptr, 320, tsum.ptr, 256
-            d.n_groups, d.T, d.HW, d.C = B, self.ctx_T, hw, 256
-            self._add(self.lib.uavsal_plan_add_tsum, d, "plan_add_tsum")
-        h2, w2 = _down(h), _down(w)
-        cx1 = self._buf("ctx1", B, h2, w2, 64)
-        self.ir_block("ctx.0", tsum, m.cxt_cb_prior[0], cx1)
-        h3, w3 = _down(h2), _down(w2)
-        cx2 = self._buf("ctx2", B, h3, w3, 64)
-        self.ir_block("ctx.1", cx1, m.cxt_cb_prior[1], cx2)
-        if self.ctx_mode == "tile":      # cb_cxt.repeat(T,1,1,1): frame k <- chunk k % B (model.py:361)
-            self.bilinear("ctx.up", cx2, cb.slice(128, 64), src_mod=B, src_div=1)
-        else:                            # independent clips: frame (c,t) <- clip c
-            self.bilinear("ctx.up", cx2, cb.slice(128, 64), src_mod=N, src_div=self.ctx_T)
-        self.join(1)
-        if PRIORS_OB_LANE != 1:
-            self.join(2)
-        self.ir_block("fucb", cb, m.fucb_layer[0], fu.slice(256, 64))
-        self.named["fust_in_cb"] = fu.slice(256, 64)
-        xf = self._buf("prefuse", N, h, w, 256)
-        self.ir_block("fucbst", fu, m.fucbst_layer[0], xf)
+        if not num_cb:                   # no prior at all: the recurrence reads fust_layer's output (model.py:346, 367)
+            xf = self._buf("prefuse", N, h, w, 256)
+            self.ir_block("fust", x, m.fust_layer[0], xf)
+        else:
+            fu = self._buf("fu320", N, h, w, 320)
+            xs = fu.slice(0, 256)
+            self.ir_block("fust", x, m.fust_layer[0], xs)
+            if use_c:
+                B = N // self.ctx_T
+                tsum = self._buf("ctx_sum", B, h, w, 256)
+                self._meta(kind="tsum", name="ctx.sum", flops=0.0, bytes=4.0 * (N + B) * hw * 256)
+                if not self._dry:
+                    d = L.TsumDesc()
+                    d.inp, d.ldi, d.out, d.ldo = xs.ptr, 320, tsum.ptr, 256
+                    d.n_groups, d.T, d.HW, d.C = B, self.ctx_T, hw, 256
+                    self._add(self.lib.uavsal_plan_add_tsum, d, "plan_add_tsum")
+                h2, w2 = _down(h), _down(w)
+                cx1 = self._buf("ctx1", B, h2, w2, 64)
+                self.ir_block("ctx.0", tsum, m.cxt_cb_prior[0], cx1)
+                h3, w3 = _down(h2), _down(w2)
+                cx2 = self._buf("ctx2", B, h3, w3, 64)
+                self.ir_block("ctx.1", cx1, m.cxt_cb_prior[1], cx2)
+                cslot = cb.slice(cb_off["ctx"], 64)
+                if self.ctx_mode == "tile":      # cb_cxt.repeat(T,1,1,1): frame k <- chunk k % B (model.py:361)
+                    self.bilinear("ctx.up", cx2, cslot, src_mod=B, src_div=1)
+                else:                            # independent clips: frame (c,t) <- clip c
+                    self.bilinear("ctx.up", cx2, cslot, src_mod=N, src_div=self.ctx_T)
+            for lane in self._prior_lanes:
+                self.join(lane)
+            self.ir_block("fucb", cb, m.fucb_layer[0], fu.slice(256, 64))
+            self.named["fust_in_cb"] = fu.slice(256, 64)
+            xf = self._buf("prefuse", N, h, w, 256)
+            self.ir_block("fucbst", fu, m.fucbst_layer[0], xf)
         self._mark("prior_fuse", s0)
 
         # ---- recurrence: ConvTWA (model_convlstm.py:276-292, 368-371) or ConvLSTM (:111-126, 206-222)
@@ -1109,18 +1129,21 @@ class Engine:
         the next call."""
         dev = self.device
         x = x.reshape(self.x_in.shape).contiguous()
-        if self.static_priors:          # (zero frame stride, checked by the model: frame 0 is every frame)
-            cb0, cb1 = cb0[:1], cb1[:1]
-        cb0 = cb0.reshape(self.cb0_in.shape).contiguous()
-        cb1 = cb1.reshape(self.cb1_in.shape).contiguous()
+        hold = [x]
         self._patch("features.0", 1 if self.in_dtype == torch.uint8 else 0, x.data_ptr())
-        self._patch("gauss.in", 0, cb0.data_ptr())
-        self._patch("ob.in", 0, cb1.data_ptr())
+        for t, stage, op, on in ((cb0, self.cb0_in, "gauss.in", self.use_priors[0]), (cb1, self.cb1_in, "ob.in", self.use_priors[1])):
+            if not on:                  # a prior this model does not have is never read (reference model.py:347-353)
+                continue
+            if self.static_priors:      # (zero frame stride, checked by the model: frame 0 is every frame)
+                t = t[:1]
+            t = t.reshape(stage.shape).contiguous()
+            self._patch(op, 0, t.data_ptr())
+            hold.append(t)
         out = torch.empty((self.N, self.h * self.w), dtype=torch.float32, device=dev)
         # (the decoder's last launch: ".dwpl" when its depthwise runs inside the projection)
         self._patch("conv_out_st.pl" if "conv_out_st.pl" in self._op_idx else "conv_out_st.dwpl", 1, out.data_ptr())
         self._patch("guard", 0, out.data_ptr())
-        hold = [x, cb0, cb1, out]
+        hold.append(out)
         st = None
         if self.persistent:
             self._stage_state_persistent(state, cstate)
@@ -1144,10 +1167,9 @@ class Engine:
 
     def stage_inputs(self, x, cb0, cb1, state, cstate=None):
         self.x_in.copy_(x.reshape(self.x_in.shape))
-        if self.static_priors:
-            cb0, cb1 = cb0[:1], cb1[:1]
-        self.cb0_in.copy_(cb0.reshape(self.cb0_in.shape))
-        self.cb1_in.copy_(cb1.reshape(self.cb1_in.shape))
+        for t, stage, on in ((cb0, self.cb0_in, self.use_priors[0]), (cb1, self.cb1_in, self.use_priors[1])):
+            if on:
+                stage.copy_((t[:1] if self.static_priors else t).reshape(stage.shape))
         if self.persistent:
             return self._stage_state_persistent(state, cstate)
         if state is None:
@@ -1196,7 +1218,8 @@ class Engine:
                 if not self.keep_taps:
                     raise RuntimeError("engine was built without taps")
                 for k in ("c3", "c4", "c5", "sfnet", "st0", "st1", "fust_in_cb", "prefuse", "rnn"):
-                    taps[k] = self.tap(k)
+                    if k in self.named:          # (no "fust_in_cb" in a model without priors)
+                        taps[k] = self.tap(k)
                 taps["logits"] = self.logits.clone().view(self.N, 1, self.h, self.w)
         return out, st
 

@@ -12,7 +12,9 @@ raises.
 
 Extension beyond the reference surface: `forward_clips` (batched independent
 clips) and the `precision` attribute selecting how fp32 data is
-fed to the matrix cores ('f32' exact fp32 MFMA, 'bf16x3' split-bf16, 'bf16').
+fed to the matrix cores ('f32' exact fp32 MFMA -- the default and the reference's own
+precision; 'f16x3' split-fp16 with fp32 accumulation, ~21 mantissa bits, <= 5e-4 on every
+golden; 'bf16x3' / 'bf16' exist as diagnostics only and do not meet 1e-3).
 """
 from __future__ import annotations
 
@@ -156,8 +158,11 @@ class UAVSal(nn.Module):
     def __init__(self, cnn_type="mobilenet_v2", time_dims=5, num_stblock=2, bias_type=[1, 1, 1],
                  iosize=[360, 640, 45, 80], planes=256, pre_model_path="", precision="f32"):
         super().__init__()
-        if list(bias_type) != [1, 1, 1]:
-            raise NotImplementedError("the HIP path implements bias_type=[1,1,1] (Demo_Test.py:125)")
+        bias_type = [int(b) for b in bias_type]
+        if len(bias_type) != 3 or any(b not in (0, 1) for b in bias_type):
+            # (the reference sizes fucb_layer as 64 * sum(bias_type) but concatenates 64 channels per enabled prior,
+            # model.py:316-318, 346-363: any other value fails there in its first forward)
+            raise ValueError("bias_type must be three 0/1 flags [gauss, observed, context] (reference model.py:281-284)")
         if planes != 256:
             raise NotImplementedError("planes=256 is the only configuration on the Demo_Test path")
         self.time_dims = time_dims
@@ -199,15 +204,21 @@ class UAVSal(nn.Module):
         self.fust_layer = nn.Sequential(dwBlock(planes, planes, kernel_size=3))
         self.use_gauss_prior, self.use_ob_prior, self.use_context_prior = bias_type
         self.num_cb = int(np.sum(np.array(bias_type) > 0))
-        self.gauss_cb_layer = nn.Sequential(dwBlock(8, 64, kernel_size=3), dwBlock(64, 64, kernel_size=3))
-        init_weights(self.gauss_cb_layer)
-        self.ob_cb_layer = nn.Sequential(dwBlock(20, 64, kernel_size=3), dwBlock(64, 64, kernel_size=3))
-        init_weights(self.ob_cb_layer)
-        self.cxt_cb_prior = nn.Sequential(dwBlock(planes, 64, kernel_size=3, stride=2),
-                                          dwBlock(64, 64, kernel_size=3, stride=2))
-        init_weights(self.cxt_cb_prior)
-        self.fucb_layer = nn.Sequential(dwBlock(192, planes // 4, kernel_size=3))
-        self.fucbst_layer = nn.Sequential(dwBlock(planes + planes // 4, planes, kernel_size=3))
+        # every prior net exists only when its flag is set, and the two fusion blocks only when any is (reference
+        # model.py:288-324): a disabled prior has no parameters and no state_dict keys
+        if self.use_gauss_prior:
+            self.gauss_cb_layer = nn.Sequential(dwBlock(8, 64, kernel_size=3), dwBlock(64, 64, kernel_size=3))
+            init_weights(self.gauss_cb_layer)
+        if self.use_ob_prior:
+            self.ob_cb_layer = nn.Sequential(dwBlock(20, 64, kernel_size=3), dwBlock(64, 64, kernel_size=3))
+            init_weights(self.ob_cb_layer)
+        if self.use_context_prior:
+            self.cxt_cb_prior = nn.Sequential(dwBlock(planes, 64, kernel_size=3, stride=2),
+                                              dwBlock(64, 64, kernel_size=3, stride=2))
+            init_weights(self.cxt_cb_prior)
+        if self.num_cb:
+            self.fucb_layer = nn.Sequential(dwBlock(64 * self.num_cb, planes // 4, kernel_size=3))
+            self.fucbst_layer = nn.Sequential(dwBlock(planes + planes // 4, planes, kernel_size=3))
         _, _, shape_r_out, shape_c_out = iosize
         rnn_cls = ConvLSTM if self.rnn_type == "lstm" else ConvTWA
         self.rnn = rnn_cls((shape_r_out, shape_c_out), planes, planes, kernel_size=(3, 3), num_layers=1,
@@ -330,10 +341,11 @@ class UAVSal(nn.Module):
         if n % self.time_dims:
             raise RuntimeError("shape '[%d, %d, ...]' is invalid for input of %d frames (model.py:357)" % (
                 n // self.time_dims, self.time_dims, n))
-        static = self.dedupe_priors and len(cb) == 2 and n > 1 and self.frame_invariant(cb, 1)
+        cb0, cb1 = self._used_cb(cb)
+        static = self.dedupe_priors and n > 1 and self._static(cb0, cb1, 1)
         eng = self._engine(x.device, 1, n, H, W, "tile", taps is not None, x.dtype, static_priors=static)
         h, w = eng.h, eng.w
-        self._check_cb(cb, n, h, w)
+        self._check_cb(cb0, cb1, n, h, w)
         st, cst = None, None
         if in_state is not None:
             st = in_state[0]
@@ -343,7 +355,7 @@ class UAVSal(nn.Module):
                 raise RuntimeError("in_state tensors must be [1, 256, %d, %d]" % (h, w))
             if st.dtype != torch.float32 or st.device != x.device:
                 raise RuntimeError("in_state must be float32 on the frames' device")
-        out, state = eng.run(x, cb[0], cb[1], st, taps, cstate=cst)
+        out, state = eng.run(x, cb0, cb1, st, taps, cstate=cst)
         if self.rnn_type == "lstm":               # reference returns last_state_list[-1] = [h, c]
             return out.view(n, 1, h, w), [state[0].view(1, 256, h, w), state[1].view(1, 256, h, w)]
         return out.view(n, 1, h, w), [state.view(1, 256, h, w)]
@@ -359,30 +371,47 @@ class UAVSal(nn.Module):
         C, T, _, H, W = x.shape
         if T < 2:
             raise RuntimeError("each clip needs at least 2 frames (reference teConv_sub, model.py:194)")
-        static = self.dedupe_priors and len(cb) == 2 and cb[0].dim() == 5 and cb[1].dim() == 5 and self.frame_invariant(cb, 2)
+        cb0, cb1 = self._used_cb(cb)
+        for t in (cb0, cb1):
+            if t is not None and (t.dim() != 5 or tuple(t.shape[:2]) != (C, T)):
+                raise RuntimeError("cb tensors must be [C, T, channels, h, w]")
+        static = self.dedupe_priors and self._static(cb0, cb1, 2)
         eng = self._engine(x.device, C, T, H, W, "clip", taps is not None, x.dtype, sync_default=False, static_priors=static)
         h, w = eng.h, eng.w
-        self._check_cb([cb[0].reshape(C * T, *cb[0].shape[2:]), cb[1].reshape(C * T, *cb[1].shape[2:])], C * T, h, w)
+        cb0 = None if cb0 is None else cb0.reshape(C * T, *cb0.shape[2:])
+        cb1 = None if cb1 is None else cb1.reshape(C * T, *cb1.shape[2:])
+        self._check_cb(cb0, cb1, C * T, h, w)
         cst = None
         if self.rnn_type == "lstm" and states is not None:
             states, cst = states                 # (h [C,256,h,w], c [C,256,h,w])
         if states is not None and tuple(states.shape) != (C, 256, h, w):
             raise RuntimeError("states must be [C, 256, h, w]")
-        out, state = eng.run(x.reshape(C * T, 3, H, W), cb[0].reshape(C * T, 8, h, w),
-                             cb[1].reshape(C * T, 20, h, w), states, taps, cstate=cst)
+        out, state = eng.run(x.reshape(C * T, 3, H, W), cb0, cb1, states, taps, cstate=cst)
         if self.rnn_type == "lstm":
             return out.view(C, T, 1, h, w), (state[0].view(C, 256, h, w), state[1].view(C, 256, h, w))
         return out.view(C, T, 1, h, w), state.view(C, 256, h, w)
 
-    @staticmethod
-    def _check_cb(cb, n, h, w):
-        if len(cb) != 2:
+    def _used_cb(self, cb):
+        """The caller's prior tensors this model reads: `cb[0]` iff the gaussian prior net exists, `cb[1]` iff the observed one
+        does (reference model.py:348-353 indexes `cb` exactly so; entries of disabled priors are never touched)."""
+        need = 2 if self.use_ob_prior else (1 if self.use_gauss_prior else 0)
+        if need and (cb is None or len(cb) < need):
             raise RuntimeError("cb must be [gauss priors, observed priors] (Demo_Test.py:14-27)")
-        if tuple(cb[0].shape) != (n, 8, h, w) or tuple(cb[1].shape) != (n, 20, h, w):
-            raise RuntimeError("cb shapes must be [%d,8,%d,%d] and [%d,20,%d,%d], got %s and %s" % (
-                n, h, w, n, h, w, tuple(cb[0].shape), tuple(cb[1].shape)))
-        if cb[0].dtype != torch.float32 or cb[1].dtype != torch.float32:
-            raise RuntimeError("cb tensors must be float32")
+        return (cb[0] if self.use_gauss_prior else None), (cb[1] if self.use_ob_prior else None)
+
+    def _static(self, cb0, cb1, frame_dims):
+        used = [t for t in (cb0, cb1) if t is not None]
+        return bool(used) and all(t.dim() > frame_dims for t in used) and self.frame_invariant(used, frame_dims)
+
+    @staticmethod
+    def _check_cb(cb0, cb1, n, h, w):
+        for t, c, what in ((cb0, 8, "gauss"), (cb1, 20, "observed")):
+            if t is None:
+                continue
+            if tuple(t.shape) != (n, c, h, w):
+                raise RuntimeError("%s priors must be [%d,%d,%d,%d], got %s" % (what, n, c, h, w, tuple(t.shape)))
+            if t.dtype != torch.float32:
+                raise RuntimeError("cb tensors must be float32")
 
 
 class UAVSAL_LSTM(UAVSal):

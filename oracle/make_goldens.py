@@ -80,10 +80,11 @@ def weights_digest(model):
     return hsh.hexdigest()
 
 
-def run_case(ref_model, name, H, W, T, B=1, seed=0, tap_stride=13, state_stride=3, calls=1, cls="UAVSal"):
+def run_case(ref_model, name, H, W, T, B=1, seed=0, tap_stride=13, state_stride=3, calls=1, cls="UAVSal", bias_type=(1, 1, 1)):
     n = B * T
     lstm = cls == "UAVSAL_LSTM"
-    model = getattr(ref_model, cls)(cnn_type="mobilenet_v2", time_dims=T, num_stblock=2, bias_type=[1, 1, 1],
+    bias_type = list(bias_type)
+    model = getattr(ref_model, cls)(cnn_type="mobilenet_v2", time_dims=T, num_stblock=2, bias_type=bias_type,
                              iosize=[H, W, H // 8, W // 8], planes=256, pre_model_path="")
     synth.load_synth_weights(model, seed)
     model.eval()
@@ -97,12 +98,15 @@ def run_case(ref_model, name, H, W, T, B=1, seed=0, tap_stride=13, state_stride=
     model.sfnet.register_forward_hook(grab("sfnet"))
     model.st_layer[0].register_forward_hook(grab("st0"))
     model.st_layer[1].register_forward_hook(grab("st1"))
-    model.fucb_layer.register_forward_hook(grab("fust_in_cb"))
-    model.fucbst_layer.register_forward_hook(grab("prefuse"))
+    tap_keys = ["sfnet", "st0", "st1", "rnn"]
+    if any(bias_type):       # (no fusion blocks in a model without priors, model.py:316)
+        model.fucb_layer.register_forward_hook(grab("fust_in_cb"))
+        model.fucbst_layer.register_forward_hook(grab("prefuse"))
+        tap_keys += ["fust_in_cb", "prefuse"]
     model.rnn.register_forward_hook(grab("rnn"))
     model.conv_out_st.register_forward_hook(grab("logits"))
 
-    rec = {"H": H, "W": W, "T": T, "B": B, "seed": seed, "calls": calls,
+    rec = {"H": H, "W": W, "T": T, "B": B, "seed": seed, "calls": calls, "bias_type": np.array(bias_type),
            "tap_stride": tap_stride, "state_stride": state_stride,
            "weights_sha256": np.frombuffer(bytes.fromhex(weights_digest(model)), dtype=np.uint8)}
     state = None
@@ -122,7 +126,7 @@ def run_case(ref_model, name, H, W, T, B=1, seed=0, tap_stride=13, state_stride=
             rec["state" + sfx] = sub(st[0], state_stride)
             rec["state_sum" + sfx] = np.float64(st[0].double().sum().item())
             if c == 0:
-                for k in ("sfnet", "st0", "st1", "fust_in_cb", "prefuse", "rnn"):
+                for k in tap_keys:
                     t = taps[k]
                     rec["tap_" + k] = sub(t, tap_stride)
     path = os.path.join(OUT, name + ".npz")
@@ -214,6 +218,12 @@ def main():
         # frames at 360x640): the context tiling quirk (model.py:357-361) and the cross-chunk temporal differences
         # (model.py:194-198) at the shape the script runs, two successive calls with the carried state
         run_case(ref_model, "e2e_360x640_B4T5_two_calls", 360, 640, 5, B=4, tap_stride=1999, state_stride=47, calls=2)
+    if not only or "bias" in only:
+        # constructor values other than the Demo default (model.py:281-324, 346-365): priors dropped one by one, and none
+        run_case(ref_model, "e2e_96x160_T4_bias101", 96, 160, 4, bias_type=(1, 0, 1))
+        run_case(ref_model, "e2e_96x160_B2T4_bias010", 96, 160, 4, B=2, bias_type=(0, 1, 0), tap_stride=29)
+        run_case(ref_model, "e2e_96x160_T4_bias000_two_calls", 96, 160, 4, bias_type=(0, 0, 0), calls=2)
+        run_case(ref_model, "e2e_96x160_B2T4_bias001", 96, 160, 4, B=2, bias_type=(0, 0, 1), tap_stride=29)
     if only and "base" not in only:
         return
     run_case(ref_model, "e2e_96x160_T4", 96, 160, 4)

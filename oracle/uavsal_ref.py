@@ -218,21 +218,27 @@ class _LSTM(nn.Module):                                     # model_convlstm.py:
 
 
 class RefUAVSal(nn.Module):
-    """model.py:254-375 (UAVSal), `cnn_type='mobilenet_v2'`, `bias_type=[1,1,1]`.
-    Same attribute names / state_dict keys as the reference (685 entries)."""
+    """model.py:254-375 (UAVSal), `cnn_type='mobilenet_v2'`, any 0/1 `bias_type` (default `[1,1,1]`: 685 entries).
+    Same attribute names / state_dict keys as the reference; a disabled prior has no module (model.py:288-324)."""
 
-    def __init__(self, time_dims=5, num_stblock=2, planes=256, rnn="twa"):
+    def __init__(self, time_dims=5, num_stblock=2, planes=256, rnn="twa", bias_type=(1, 1, 1)):
         super().__init__()
         self.time_dims = time_dims
+        self.use_gauss_prior, self.use_ob_prior, self.use_context_prior = (int(b) for b in bias_type)   # model.py:281-283
+        self.num_cb = sum(1 for b in bias_type if b > 0)                                                 # :284
         self.rnn_type = rnn      # "lstm" = the reference's UAVSAL_LSTM (model.py:960-1076)
         self.sfnet = _SRFNet(planes)
         self.st_layer = nn.Sequential(*[_STBlock(planes, planes // 32) for _ in range(num_stblock)])
         self.fust_layer = nn.Sequential(_IRBlock(planes, planes))
-        self.gauss_cb_layer = nn.Sequential(_IRBlock(8, 64), _IRBlock(64, 64))
-        self.ob_cb_layer = nn.Sequential(_IRBlock(20, 64), _IRBlock(64, 64))
-        self.cxt_cb_prior = nn.Sequential(_IRBlock(planes, 64, stride=2), _IRBlock(64, 64, stride=2))
-        self.fucb_layer = nn.Sequential(_IRBlock(192, planes // 4))
-        self.fucbst_layer = nn.Sequential(_IRBlock(planes + planes // 4, planes))
+        if self.use_gauss_prior:                                                                         # :289-296
+            self.gauss_cb_layer = nn.Sequential(_IRBlock(8, 64), _IRBlock(64, 64))
+        if self.use_ob_prior:                                                                            # :298-305
+            self.ob_cb_layer = nn.Sequential(_IRBlock(20, 64), _IRBlock(64, 64))
+        if self.use_context_prior:                                                                       # :307-314
+            self.cxt_cb_prior = nn.Sequential(_IRBlock(planes, 64, stride=2), _IRBlock(64, 64, stride=2))
+        if self.num_cb:                                                                                  # :316-324
+            self.fucb_layer = nn.Sequential(_IRBlock(64 * self.num_cb, planes // 4))
+            self.fucbst_layer = nn.Sequential(_IRBlock(planes + planes // 4, planes))
         self.rnn = _LSTM(planes, planes) if rnn == "lstm" else _TWA(planes, planes)
         self.conv_out_st = _IRBlock(planes, 1)
 
@@ -249,17 +255,24 @@ class RefUAVSal(nn.Module):
                 taps[f"st{i}"] = x
         x = self.fust_layer(x)
         n, c, h, w = x.shape
-        cb_g = self.gauss_cb_layer(cb[0])                            # model.py:349
-        cb_o = self.ob_cb_layer(cb[1])                               # :352
-        B = n // T
-        ctx = x.contiguous().view(B, T, c, h, w).sum(1)             # :357-358
-        ctx = self.cxt_cb_prior(ctx)
-        ctx = F.interpolate(ctx, size=(h, w), mode="bilinear", align_corners=True)
-        ctx = ctx.repeat(T, 1, 1, 1)                                 # :361 (tiles, not interleaves)
-        x_cb = self.fucb_layer(torch.cat([cb_g, cb_o, ctx], 1))      # :363-364
-        x = self.fucbst_layer(torch.cat([x, x_cb], 1))               # :365
+        if self.num_cb:                                                  # model.py:346
+            cb_fu = []
+            if self.use_gauss_prior:
+                cb_fu.append(self.gauss_cb_layer(cb[0]))                 # :349
+            if self.use_ob_prior:
+                cb_fu.append(self.ob_cb_layer(cb[1]))                    # :352
+            if self.use_context_prior:
+                B = n // T
+                ctx = x.contiguous().view(B, T, c, h, w).sum(1)         # :357-358
+                ctx = self.cxt_cb_prior(ctx)
+                ctx = F.interpolate(ctx, size=(h, w), mode="bilinear", align_corners=True)
+                cb_fu.append(ctx.repeat(T, 1, 1, 1))                     # :361 (tiles, not interleaves)
+            x_cb = self.fucb_layer(torch.cat(cb_fu, 1))                  # :363-364
+            x = self.fucbst_layer(torch.cat([x, x_cb], 1))               # :365
+            if taps is not None:
+                taps.update(fust_in_cb=x_cb)
         if taps is not None:
-            taps.update(fust_in_cb=x_cb, prefuse=x)
+            taps.update(prefuse=x)
         if self.rnn_type == "lstm":      # in_state = None or [(h, c)]; returns [h, c]
             hc = in_state[0] if in_state is not None else (x.new_zeros(1, c, h, w), x.new_zeros(1, c, h, w))
             seq, (h_last, c_last) = self.rnn(x.view(1, n, c, h, w), hc)
@@ -288,7 +301,7 @@ class RefUAVSal(nn.Module):
         try:
             for c in range(C):
                 st = None if states is None else [states[c:c + 1]]
-                o, s = self.forward(x[c], [cb[0][c], cb[1][c]], st)
+                o, s = self.forward(x[c], [None if t is None else t[c] for t in cb], st)
                 outs.append(o)
                 sts.append(s[0])
         finally:
@@ -307,9 +320,9 @@ def convlstm_cell_step(weight: torch.Tensor, x_t: torch.Tensor, h: torch.Tensor,
     return o * torch.tanh(c_next), c_next
 
 
-def build_oracle(time_dims=5, seed=0, rnn="twa") -> RefUAVSal:
+def build_oracle(time_dims=5, seed=0, rnn="twa", bias_type=(1, 1, 1)) -> RefUAVSal:
     """Oracle model in eval mode with the deterministic synthetic weights."""
     from iip_uavsal_saliency_amd import synth
-    m = RefUAVSal(time_dims=time_dims, rnn=rnn)
+    m = RefUAVSal(time_dims=time_dims, rnn=rnn, bias_type=bias_type)
     synth.load_synth_weights(m, seed)
     return m.eval()

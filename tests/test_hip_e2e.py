@@ -101,6 +101,57 @@ def test_forward_vs_reference_golden(hip_model, golden_dir, name, prec):
     assert all(e.streamk_clean() for e in hip_model._engines.values())
 
 
+@pytest.mark.parametrize("prec", PARITY_PRECS)
+@pytest.mark.parametrize("name", ["e2e_96x160_T4_bias101", "e2e_96x160_B2T4_bias010", "e2e_96x160_T4_bias000_two_calls",
+                                  "e2e_96x160_B2T4_bias001"])
+def test_every_bias_type_vs_reference_golden(golden_dir, name, prec):
+    """Constructor values other than the Demo default (reference model.py:281-324, 346-365): a disabled prior has no net (and
+    its `cb` entry is never read), the concat keeps the order gauss | observed | context, `fucb_layer` takes 64 channels per
+    enabled prior, and with no prior at all the recurrence reads `fust_layer`'s output.  Against the reference's own outputs;
+    the oracle is run beside it for the taps."""
+    from iip_uavsal_saliency_amd import UAVSal
+    from oracle.uavsal_ref import build_oracle
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    H, W, T, B = int(g["H"]), int(g["W"]), int(g["T"]), int(g["B"])
+    bias = [int(b) for b in g["bias_type"]]
+    m = UAVSal(time_dims=T, bias_type=bias)
+    synth.load_synth_weights(m, int(g["seed"]))
+    m = m.cuda().eval()
+    assert m.num_cb == sum(bias) and hasattr(m, "fucb_layer") == bool(sum(bias))
+    ora = build_oracle(time_dims=T, seed=int(g["seed"]), bias_type=bias)
+    assert list(m.state_dict().keys()) == list(ora.state_dict().keys())
+    n = B * T
+    state = None
+    for c in range(int(g["calls"])):
+        x, cb = make_inputs(n, H, W, int(g["seed"]), t0=c * n)
+        taps = {}
+        # entries of disabled priors are never touched: hand over None in their place (the reference only indexes what it uses)
+        cbd = [cb[0] if bias[0] else None, cb[1] if bias[1] else None]
+        if not bias[1]:
+            cbd = cbd[:1] if bias[0] else []
+        m.precision = prec
+        out, st = m(x.cuda(), [None if t is None else t.cuda() for t in cbd],
+                    None if state is None else [state.cuda()], taps)
+        out, st = out.cpu(), st[0].cpu()
+        state = st
+        sfx = "" if c == 0 else f"_call{c}"
+        err = np.abs(out.numpy() - g["out" + sfx]).max()
+        lerr = np.abs(taps["logits"].cpu().numpy() - g["logits" + sfx]).max()
+        serr = np.abs(st.contiguous().view(-1).numpy()[::int(g["state_stride"])] - g["state" + sfx]).max()
+        print("%s %s call %d: map %.3e logits %.3e state %.3e" % (name, prec, c, err, lerr, serr))
+        assert err <= MAP_TOL[prec], (name, prec, c, err)
+        assert lerr <= 2 * LOGIT_TOL[prec], (name, prec, c, lerr)
+        assert serr <= STATE_TOL[prec], (name, prec, c, serr)
+        if c == 0:
+            for k in ("sfnet", "st1", "fust_in_cb", "prefuse", "rnn"):
+                if "tap_" + k not in g:
+                    assert not any(bias) and k in ("fust_in_cb", "prefuse")
+                    continue
+                tap = taps[k].cpu().contiguous().view(-1).numpy()[::int(g["tap_stride"])]
+                assert np.abs(tap - g["tap_" + k]).max() <= TAP_REL[prec] * max(1.0, np.abs(g["tap_" + k]).max()), (name, k)
+    assert all(e.streamk_clean() for e in m._engines.values())
+
+
 @pytest.mark.parametrize("prec", ["f32", "f16x3"])
 def test_demo_default_call_at_full_size_vs_reference_golden(hip_model, golden_dir, prec):
     """Demo_Test.py:110-125 as it really runs: batch_size=4, time_dims=5 -> ONE forward of 20 frames at 360x640

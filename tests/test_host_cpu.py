@@ -259,6 +259,90 @@ def test_sharded_forward_equals_single_process_gloo_world2():
     assert np.array_equal(got[0][0], got[1][0])
 
 
+def _clips(C, T, H, W):
+    """C distinct clips (clip c seeded with c, bench.py's convention), so a gathered tensor in the wrong order cannot pass."""
+    h, w = H // 8, W // 8
+    xs = [torch.from_numpy(synth.normalize_frames(synth.synth_frames_u8(T, H, W, c))) for c in range(C)]
+    g = [torch.from_numpy(synth.gauss_priors(T, h, w)) for _ in range(C)]
+    o = [torch.from_numpy(synth.ob_priors(T, h, w, seed=c)) for c in range(C)]
+    return torch.stack(xs), [torch.stack(g), torch.stack(o)]
+
+
+def _worker_w4(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from iip_uavsal_saliency_amd.parallel import ClipShard, forward_clips_sharded
+    from oracle.uavsal_ref import build_oracle
+    model = build_oracle(time_dims=2)
+    C, T, H, W = 8, 2, 72, 104
+    x, cb = _clips(C, T, H, W)
+    sh = ClipShard(C, world, rank)
+    # production form: the rank hands over only its own two clips, total_clips names the batch
+    out, st = forward_clips_sharded(model, sh.local(x).clone(), [sh.local(cb[0]).clone(), sh.local(cb[1]).clone()], total_clips=C)
+    q.put((rank, sh.first, sh.count, out.numpy(), st.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_forward_gloo_world4_rank_order_is_clip_order():
+    """W > 2: four ranks x two clips through `forward_clips_sharded(..., total_clips=8)` -- the gathered maps are in clip order
+    on every rank (rank r's block at [2r, 2r + 2)), every clip differs from every other, states stay on their rank."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    W_ = 4
+    procs = [ctx.Process(target=_worker_w4, args=(r, W_, port, q)) for r in range(W_)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(W_):
+        r, first, count, out, st = q.get(timeout=300)
+        got[r] = (first, count, out, st)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from oracle.uavsal_ref import build_oracle
+    model = build_oracle(time_dims=2)
+    x, cb = _clips(8, 2, 72, 104)
+    ref_out, ref_st = model.forward_clips(x, cb)
+    ref = ref_out.numpy()
+    # the clips are told apart by more than the comparison tolerance (else the order check below would be vacuous)
+    assert min(np.abs(ref[a] - ref[b]).max() for a in range(8) for b in range(a)) > 1e-3
+    for r in range(W_):
+        first, count, out, st = got[r]
+        assert (first, count) == (2 * r, 2) and out.shape == ref.shape
+        # (the ranks run one thread each, this process all of them: oneDNN's summation order differs by ~1e-6)
+        assert np.abs(out - ref).max() < 1e-4                                     # all eight maps, clip order
+        assert np.abs(st - ref_st[first:first + count].numpy()).max() < 1e-4      # only its own two states
+        assert np.array_equal(out, got[0][2])                                     # bit-identical on every rank
+
+
+def test_every_bias_type_builds_the_reference_module_tree():
+    """reference model.py:281-324: a prior net exists iff its flag is set; the two fusion blocks iff any is; `fucb_layer` takes
+    64 channels per enabled prior.  Same keys and shapes as the oracle tree for all eight flag sets (the [1,1,1] tree is pinned to
+    the reference's 51.59 MB known answer; the oracle's other trees to reference goldens in tests/test_oracle_golden.py)."""
+    import itertools
+    from iip_uavsal_saliency_amd import UAVSal
+    from oracle.uavsal_ref import RefUAVSal
+    for bias in itertools.product((0, 1), repeat=3):
+        m, r = UAVSal(bias_type=list(bias)), RefUAVSal(bias_type=bias)
+        sd, rd = m.state_dict(), r.state_dict()
+        assert list(sd.keys()) == list(rd.keys()) and all(sd[k].shape == rd[k].shape for k in sd), bias
+        assert (m.use_gauss_prior, m.use_ob_prior, m.use_context_prior) == bias and m.num_cb == sum(bias)
+        for attr, on in (("gauss_cb_layer", bias[0]), ("ob_cb_layer", bias[1]), ("cxt_cb_prior", bias[2]),
+                         ("fucb_layer", any(bias)), ("fucbst_layer", any(bias))):
+            assert hasattr(m, attr) == bool(on), (bias, attr)
+        if any(bias):
+            assert m.fucb_layer[0].conv[0][0].weight.shape[1] == 64 * sum(bias)
+    with pytest.raises(ValueError):
+        UAVSal(bias_type=[1, 2, 0])
+    with pytest.raises(ValueError):
+        UAVSal(bias_type=[1, 1])
+
+
 def test_reference_style_whole_model_pickle_loads_through_the_shim(tmp_path):
     """A whole pickled model whose classes live in `model`, `model_feature`, `model_convlstm` and
     `torchvision.models.mobilenet` (as the reference's checkpoints do, Demo_Train_Test.py:159-160)

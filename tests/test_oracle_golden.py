@@ -10,6 +10,8 @@ from iip_uavsal_saliency_amd import synth
 from oracle import uavsal_ref as R
 
 CASES = ["e2e_96x160_T4", "e2e_96x160_B4T5", "e2e_96x160_T4_two_calls", "e2e_72x104_T3"]
+# constructor values other than the Demo default: priors dropped one by one, and none (reference model.py:281-324, 346-365)
+BIAS = ["e2e_96x160_T4_bias101", "e2e_96x160_B2T4_bias010", "e2e_96x160_T4_bias000_two_calls", "e2e_96x160_B2T4_bias001"]
 BIG = ["e2e_288x512_T8",
        # Demo_Test.py's own call at its real size: one forward of 4 x 5 = 20 frames at 360x640, twice (carried state)
        "e2e_360x640_B4T5_two_calls"]
@@ -41,11 +43,12 @@ def test_oracle_lstm_matches_reference_golden(golden_dir):
         np.testing.assert_allclose(_sub(st[1], int(g["state_stride"])), g["cstate" + sfx], rtol=0, atol=2e-5)
 
 
-@pytest.mark.parametrize("name", CASES + BIG)
+@pytest.mark.parametrize("name", CASES + BIAS + BIG)
 def test_oracle_matches_reference_golden(name, golden_dir):
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     H, W, T, B = int(g["H"]), int(g["W"]), int(g["T"]), int(g["B"])
-    model = R.build_oracle(time_dims=T, seed=int(g["seed"]))
+    bias = tuple(int(b) for b in g["bias_type"]) if "bias_type" in g else (1, 1, 1)
+    model = R.build_oracle(time_dims=T, seed=int(g["seed"]), bias_type=bias)
     n = B * T
     state = None
     for c in range(int(g["calls"])):
@@ -60,6 +63,9 @@ def test_oracle_matches_reference_golden(name, golden_dir):
         np.testing.assert_allclose(_sub(st[0], int(g["state_stride"])), g["state" + sfx], rtol=0, atol=2e-5)
         if c == 0:
             for k in ("sfnet", "st0", "st1", "fust_in_cb", "prefuse", "rnn"):
+                if not any(bias) and k in ("fust_in_cb", "prefuse"):
+                    assert "tap_" + k not in g          # no fusion blocks in a model without priors
+                    continue
                 np.testing.assert_allclose(_sub(taps[k], int(g["tap_stride"])), g["tap_" + k], rtol=0, atol=5e-5)
 
 
