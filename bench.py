@@ -63,7 +63,9 @@ def kernel_symbol(prec, tile, taps, streamk=0, split=False):
     return "conv_gemm_kernel<%s>" % (H16_INST[tile] % (PREC_ID[prec], taps))
 
 
-PROFILE_ROUND = "r4"
+PROFILE_ROUND = "r5"
+PER_OP_TIMING = ("isolated: hipEvents around each op of the plan on the launch stream; per op the MIN of 2 x 5-launch means "
+                 "(rounds 1-3: one 5-launch mean), back to back on the same buffers, after one run of the ops in front of it")
 
 
 def _wl_tag(C, T, H, W, prec):
@@ -178,7 +180,11 @@ def kernel_rooflines(eng, prec, iters=5):
     groups = {}
     for i, m in enumerate(eng.ops_meta):
         # two measurements, the smaller one: a one-off stall of the box (tens of ms, seen a few times per hour on this pool) inside
-        # a 5-launch average would otherwise own the whole family figure
+        # a 5-launch average would otherwise own the whole family figure.  The ops in front of it are run once first: activations
+        # share addresses by liveness (engine.py, arena), so after a full forward an op's inputs have been overwritten by later
+        # buffers -- the timed launches must read the data they read in a forward (ReLU6 zeros and all: the fp32 GEMMs run ~15 %
+        # slower on random operands than on half-zero ones)
+        eng.run_ops(0, i)
         ms = min(eng.time_ops(i, i + 1, iters), eng.time_ops(i, i + 1, iters))
         if m["kind"].startswith("conv"):
             key = kernel_symbol(prec, m["tile"], 9 if m["kind"] == "conv3" else 1, m.get("streamk", 0), m.get("split", False))
@@ -241,6 +247,25 @@ def depthwise_family(groups):
     return fam
 
 
+def family_in_loop(fam, C, T, H, W, prec):
+    """The same depthwise launches INSIDE the timed loop: per instance the rocprofv3 average duration (committed kernel-stats
+    summary of this bench command, stamped with the kernel sources) x its launches per step; neither warmed by back-to-back
+    repeats on the same buffers (the isolated figure is) -- but stretched wherever another lane's kernels share the chip."""
+    us, miss = 0.0, []
+    for inst, rec in fam["instances"].items():
+        il = in_loop_timing(inst, C, T, H, W, prec)
+        if il.get("status") != "ok":
+            miss.append(inst)
+            status = il.get("status")
+            continue
+        us += il["avg_launch_us"] * rec["launches"]
+    if miss:
+        return {"status": status, "missing": miss, "file": inloop_file(C, prec, T, H, W)}
+    gbs = fam["alg_mb_per_step"] * 1e6 / (us * 1e-6) / 1e9
+    return {"status": "ok", "file": inloop_file(C, prec, T, H, W), "kernel_ms_per_step": round(us * 1e-3, 4),
+            "achieved": round(gbs, 1), "frac": round(gbs / PEAK_HBM_GBS, 4)}
+
+
 def fused_family(groups, mid=False):
     """Fused inverted-residual launches: fused-floor bytes (block input + output [+ residual read]) / time.
     `mid`: the mid-channel kernel's launches (features[8..13]) instead of the small-channel kernel's (features[1..7]) -- a
@@ -282,6 +307,46 @@ def dwproj_family(groups, prec):
             "instances": {k: {"launches": g["launches"], "ms": round(g["ms"], 4)} for k, g in fu.items()}}
 
 
+def reference_shape(model, args, device, H, W, n, time_dims, surface, with_cpu):
+    """One of the reference's own call shapes on the HIP path: frames/s over the same timed windows as the headline, first
+    call of the new shape, parity and speed of the CPU oracle on the same inputs."""
+    from iip_uavsal_saliency_amd import synth
+    h, w = H // 8, W // 8
+    x = torch.from_numpy(synth.normalize_frames(synth.synth_frames_u8(n, H, W, 0)))
+    cb = [torch.from_numpy(synth.gauss_priors(n, h, w)), torch.from_numpy(synth.ob_priors(n, h, w, seed=0))]
+    xd, cbd = x.to(device), [cb[0].to(device), cb[1].to(device)]
+    model.time_dims = time_dims
+    if surface == "forward":            # UAVSal.forward(x [B*T,3,H,W], cb, [state]) as Demo_Test.py:85 calls it
+        st0 = torch.zeros((1, 256, h, w), device=device)
+        fn = lambda: model(xd, cbd, [st0])
+    else:
+        xc, cbc = xd[None], [cbd[0][None], cbd[1][None]]
+        fn = lambda: model.forward_clips(xc, cbc, None)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    out, _ = fn()
+    torch.cuda.synchronize(device)
+    first = (time.perf_counter() - t0) * 1e3
+    wins = [timed_steps(fn, args.steps, args.warmup if i == 0 else 0, False, device) for i in range(max(1, args.windows))]
+    dt = sorted(wins)[len(wins) // 2]
+    rec = {"workload": "%dx%d, %d frames, time_dims=%d, UAVSal.%s, prec=%s" % (H, W, n, time_dims, surface, args.prec),
+           "value": round(n * args.steps / dt, 2), "unit": "frames/s", "ms_per_call": round(dt / args.steps * 1e3, 4),
+           "windows_ms_per_call": [round(w_ / args.steps * 1e3, 4) for w_ in wins], "steps": args.steps,
+           "first_call_ms": round(first, 1),
+           "note": "forward() waits for its own launches before returning (the reference's caller reads the map at once, Demo_Test.py:87)"
+           if surface == "forward" else "forward_clips: asynchronous, as the headline"}
+    if with_cpu:
+        from oracle.uavsal_ref import build_oracle       # checker / baseline only
+        oracle = build_oracle(time_dims=time_dims, seed=0)
+        t0 = time.perf_counter()
+        ref, _ = oracle(x, cb, None)
+        cpu_s = time.perf_counter() - t0
+        rec["max_abs_map_vs_cpu_ref"] = float("%.3e" % (out.reshape(ref.shape).cpu() - ref).abs().max().item())
+        rec["cpu_oracle_frames_per_s"] = round(n / cpu_s, 3)
+        rec["cpu_oracle_sample"] = "one pass of the same %d frames on %d host threads (%.1f s)" % (n, torch.get_num_threads(), cpu_s)
+    return rec
+
+
 def timed_steps(fn, steps, warmup, distributed, device):
     for _ in range(warmup):
         fn()
@@ -303,19 +368,39 @@ def timed_steps(fn, steps, warmup, distributed, device):
 
 
 def visible_gpus():
-    """GPUs this process could use, WITHOUT initialising HIP (the launcher must stay GPU-free: its children are fresh
-    processes).  `UAVSAL_BENCH_VISIBLE_GPUS` overrides the count for the CPU test of the launcher."""
+    """GPUs this process could use, counted WITHOUT a HIP call: the visibility variables first, else the KFD topology
+    (/sys/class/kfd/kfd/topology/nodes/*/properties: a node with simd_count > 0 is a GPU).  Only when neither can be read
+    does it fall back to torch.cuda.device_count(), which on this image may call hipGetDeviceCount (amdsmi absent) -- that is
+    harmless here because the launcher never execs and never runs under rocprofv3: its ranks are fresh child processes.
+    `UAVSAL_BENCH_VISIBLE_GPUS` overrides the count for the CPU test of the launcher."""
     if "UAVSAL_BENCH_VISIBLE_GPUS" in os.environ:
         return int(os.environ["UAVSAL_BENCH_VISIBLE_GPUS"])
-    return int(torch.cuda.device_count())
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([t for t in v.split(",") if t.strip() != ""])
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for node in os.listdir(base):
+            for line in open(os.path.join(base, node, "properties")):
+                k, _, val = line.partition(" ")
+                if k == "simd_count" and int(val) > 0:
+                    n += 1
+        return n
+    except (OSError, ValueError):
+        return int(torch.cuda.device_count())
 
 
-def self_launch(n, argv, worker=None, poll_s=0.2):
+def self_launch(n, argv, worker=None, poll_s=0.2, deadline_s=None):
     """`python bench.py --gpus N` without a launcher around it: start N fresh rank processes of this script (one per
     GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, rendezvous on 127.0.0.1), let rank 0's JSON line
     through on stdout, and return non-zero if any rank fails (the surviving ranks are stopped by PID: they would wait in
     a collective for ever).  Fails loudly when fewer than N GPUs are visible -- it never measures a smaller job.
-    `worker`: the command to run per rank (default: this script with the same arguments); tests pass a stub."""
+    `worker`: the command to run per rank (default: this script with the same arguments); tests pass a stub.
+    `deadline_s` (default `UAVSAL_BENCH_DEADLINE_S`, 3000): wall-clock limit for the whole job -- ranks stuck in a collective
+    or on a hung GPU never exit by themselves; on expiry the ranks still alive are named, stopped by PID, and the launcher
+    returns 124."""
     import socket
     import subprocess
     have = visible_gpus()
@@ -337,7 +422,13 @@ def self_launch(n, argv, worker=None, poll_s=0.2):
         procs.append(subprocess.Popen(cmd, env=env))
     failed = None
     live = set(range(n))
+    if deadline_s is None:
+        deadline_s = float(os.environ.get("UAVSAL_BENCH_DEADLINE_S", "3000"))
+    t_end = time.monotonic() + deadline_s
     while live and failed is None:
+        if time.monotonic() > t_end:
+            failed = (-1, 124)
+            break
         for r in sorted(live):
             rc = procs[r].poll()
             if rc is None:
@@ -357,6 +448,10 @@ def self_launch(n, argv, worker=None, poll_s=0.2):
             except subprocess.TimeoutExpired:
                 procs[r].kill()
                 procs[r].wait()
+        if failed[0] < 0:
+            print("bench.py: no result after %.0f s; rank(s) %s were still running and have been stopped" % (deadline_s, sorted(live)),
+                  file=sys.stderr, flush=True)
+            return 124
         print("bench.py: rank %d exited with code %d; %d other rank(s) stopped" % (failed[0], failed[1], len(live)),
               file=sys.stderr, flush=True)
         return failed[1] if 0 < failed[1] < 256 else 1
@@ -456,7 +551,14 @@ def main():
             gather_maps(out, gathered)
         last["out"], last["state"] = out, st
 
-    log("model + inputs ready; timing %d steps" % args.steps)
+    # first-call latency: weight packing (BN folding, GEMM / Winograd layouts, upload) + sizing pass + plan recording + the
+    # first launches.  Demo_Test.py:75-86 pays it once per video shape -- and once more (plan only) for a short last group
+    torch.cuda.synchronize(device)
+    t_first = time.perf_counter()
+    step()
+    torch.cuda.synchronize(device)
+    first_call_ms = (time.perf_counter() - t_first) * 1e3
+    log("model + inputs ready (first call %.0f ms); timing %d steps" % (first_call_ms, args.steps))
     # every window is exactly --steps steps between barrier + synchronize on both sides (max over ranks);
     # the median window is the reported one, all of them are listed
     wins = [timed_steps(step, args.steps, args.warmup if i == 0 else 0, distributed, device)
@@ -486,6 +588,14 @@ def main():
                                "partition, gather and timing protocol only; value is NOT a multi-GPU figure" % world)
         result["config"]["parallelism"] = "REHEARSAL: %d ranks on one GPU, gloo" % world
     result["peak_device_memory_mb"] = round(torch.cuda.max_memory_allocated(device) / 1e6, 1)      # weights + plan buffers + inputs
+    result["first_call_ms"] = round(first_call_ms, 1)
+    result["first_call_note"] = "weight packing + upload + plan sizing / recording + first launches of this workload (one per model and shape)"
+    try:
+        eng0 = list(model._engines.values())[-1]
+        result["activation_arena"] = dict({k: round(v, 1) if isinstance(v, float) else v for k, v in eng0.arena_stats.items()},
+                                          note="one pool per plan placed by liveness; unshared_mb = one allocation per activation (rounds 1-4)")
+    except Exception:
+        pass
     if distributed and not args.no_extra:
         # the like-for-like origin of the weak-scaling curve, in the line itself: the SAME per-GPU workload on rank 0's GPU
         # alone (no gather, the other ranks wait in the barrier), and value / (N x that)
@@ -511,7 +621,8 @@ def main():
             result["roofline"] = roofline_obj(dom[0], dom[1], args.prec)
             result["roofline"]["share_of_kernel_time"] = round(dom[1]["ms"] / tot, 3)
             result["roofline"]["traffic"], result["roofline"]["traffic_source"] = measured_traffic(dom[0], C, T, H, W, args.prec)
-            result["roofline"]["timing"] = "isolated: hipEvents around each op of the plan on the launch stream, 5 back-to-back repeats"
+            result["roofline"]["timing"] = PER_OP_TIMING
+            result["per_op_timing"] = PER_OP_TIMING
             il = in_loop_timing(dom[0], C, T, H, W, args.prec)
             if il.get("status") == "ok":       # the same launches inside the overlapped timed loop (rocprofv3 average)
                 per_launch = dom[1]["flops"] / dom[1]["launches"]
@@ -526,6 +637,8 @@ def main():
                 big = "dw3x3_kernel<1, 4, 4>"
                 if big in fam["instances"]:
                     fam["instances"][big]["traffic"], _ = measured_traffic(big, C, T, H, W, args.prec)
+                fam["in_loop"] = family_in_loop(fam, C, T, H, W, args.prec)
+                fam["timing"] = PER_OP_TIMING
                 result["roofline_dw"] = fam
             dots = {k: g for k, g in groups.items() if g["kind"] == "dw_dot"}
             for k, g in dots.items():
@@ -552,12 +665,16 @@ def main():
                     rec["fused_floor_mb_per_launch"] = round(groups[inst]["bytes"] / groups[inst]["launches"] / 1e6, 3)
                 result["roofline_dwproj"] = dwp
             result["kernel_time_ms"] = {k: round(v["ms"], 4) for k, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])}
-            result["stage_time_ms"] = {k: round(eng.time_ops(a, b, 5), 4) for k, (a, b) in eng.stage_ranges.items()}
+            result["stage_time_ms"] = {}
+            for k, (a, b) in eng.stage_ranges.items():
+                eng.run_ops(0, a)
+                result["stage_time_ms"][k] = round(eng.time_ops(a, b, 5), 4)
         if not args.no_cpu_baseline:
-            if args.persistent_state:       # the parity check below compares a zero-state call
-                model.persistent_state = False
-                last["out"], last["state"] = model.forward_clips(x, cb, state)
-                model.persistent_state = True
+            # the parity check below compares a fresh zero-state call (the per-op timing above re-ran single launches of the plan
+            # into the last step's output tensors)
+            model.persistent_state = False
+            last["out"], last["state"] = model.forward_clips(x, cb, state)
+            model.persistent_state = bool(args.persistent_state)
             from oracle.uavsal_ref import build_oracle       # checker / baseline only
             cores = host_cores()
             torch.set_num_threads(cores)
@@ -594,10 +711,14 @@ def main():
             x8, cb8 = make_clips(8, T, H, W)
             x8 = x8.to(device)
             cb8 = [cb8[0].to(device), cb8[1].to(device)]
-            ks = max(3, args.steps // 4)
-            dt8 = timed_steps(lambda: model.forward_clips(x8, cb8, None), ks, 1, False, device)
+            ks = args.steps
+            w8 = [timed_steps(lambda: model.forward_clips(x8, cb8, None), ks, args.warmup if i == 0 else 0, False, device)
+                  for i in range(max(1, args.windows))]
+            dt8 = sorted(w8)[len(w8) // 2]
             result["scaling_reference"] = {"workload": "%dx%d batch=8 clip(s)/GPU seq=%d, prec=%s (what --gpus N>1 runs per GPU)" % (H, W, T, args.prec),
                                            "value": round(8 * T * ks / dt8, 2), "unit": "frames/s", "n_gpus": 1, "steps": ks,
+                                           "ms_per_step": round(dt8 / ks * 1e3, 4),
+                                           "windows_ms_per_step": [round(w_ / ks * 1e3, 4) for w_ in w8],
                                            "note": "origin of the weak-scaling curve: an N-GPU line's efficiency is value / (N x this), "
                                                    "NOT value / (N x this line's 1-clip value)"}
             if not args.no_roofline:
@@ -609,11 +730,28 @@ def main():
                 if fam8:
                     fam8["workload"] = result["scaling_reference"]["workload"]
                     fam8["share_of_kernel_time"] = round(fam8["kernel_ms_per_step"] / sum(g["ms"] for g in g8.values()), 3)
+                    fam8["in_loop"] = family_in_loop(fam8, 8, T, H, W, args.prec)
+                    fam8["timing"] = PER_OP_TIMING
                     result["scaling_reference"]["roofline_dw"] = fam8
                 fus8 = fused_family(g8)
                 if fus8:
                     result["scaling_reference"]["roofline_fused"] = fus8
             del x8, cb8
+            model.invalidate_engines()
+        if not args.no_extra and (H, W, T, C) == (360, 640, 8, 1):
+            # the reference's own shapes, timed (they were parity runs only): the ONE call its caller makes (Demo_Test.py:110-125:
+            # batch_size 4 x time_dims 5 -> forward() of 20 frames at 360x640, state carried) and the only speed it publishes
+            # (README.md:104: 288x512, "85FPS", hardware not stated).  Each with max-abs vs the CPU oracle on the same inputs
+            # and the oracle's own frames/s (one pass, all host threads).  Same model object: weights are packed already, so
+            # `first_call_ms` here is what a second shape costs (plan sizing + recording + first launches)
+            for tag, (h2, w2, n2, td, surface) in (("extra_demo_default", (360, 640, 20, 5, "forward")),
+                                                   ("extra_288x512", (288, 512, 8, 8, "forward_clips"))):
+                try:
+                    log("%s: %d frames at %dx%d through %s" % (tag, n2, h2, w2, surface))
+                    result[tag] = reference_shape(model, args, device, h2, w2, n2, td, surface, not args.no_cpu_baseline)
+                except Exception as e:
+                    result[tag] = {"error": repr(e)[:300]}
+            model.time_dims = T
             model.invalidate_engines()
         if not args.no_extra and args.prec == "f32":
             # the same workload, and BASELINE.json's configs[2] shape, in the split-fp16 precision
@@ -664,6 +802,7 @@ def main():
                     cbv = [c[:1, :1].expand(C, T, -1, -1, -1) for c in cb]
                     dts = timed_steps(lambda: model.forward_clips(x, cbv, state), args.steps, 3, False, device)
                     ov, _ = model.forward_clips(x, cbv, state)
+                    last["out"], _ = model.forward_clips(x, cb, state)
                     result["extra_frame_invariant_priors"] = {
                         "value": round(C * T * args.steps / dts, 2), "unit": "frames/s", "ms_per_step": round(dts / args.steps * 1e3, 4),
                         "max_abs_vs_value_path": float("%.3e" % (ov - last["out"]).abs().max().item()),

@@ -104,6 +104,10 @@ class CopyDesc(C.Structure):
                 ("row_floats", C.c_int64), ("rows", C.c_int32)]
 
 
+class FillDesc(C.Structure):
+    _fields_ = [("out", _f), ("n", C.c_int64), ("bits", C.c_uint32)]
+
+
 class FusedIrDesc(C.Structure):
     _fields_ = [("inp", _f), ("ldi", C.c_int32), ("w1", _f), ("scale1", _f), ("bias1", _f),
                 ("wd", _f), ("scale_d", _f), ("bias_d", _f), ("w2", _f), ("scale2", _f), ("bias2", _f),
@@ -124,7 +128,7 @@ class WinoDesc(C.Structure):
 
 
 DESC_TYPES = [ConvDesc, DwDesc, StemDesc, BilinearDesc, TdiffDesc, TsumDesc, LayoutDesc, PostDesc, GuardDesc, CopyDesc,
-              FusedIrDesc, WinoDesc, DwDotDesc]
+              FusedIrDesc, WinoDesc, DwDotDesc, FillDesc]
 
 # every symbol include/uavsal_hip.h declares: (name, restype, argtypes)
 SYMBOLS = [
@@ -145,6 +149,8 @@ SYMBOLS = [
     ("uavsal_postprocess", C.c_int, [C.POINTER(PostDesc), C.c_void_p]),
     ("uavsal_guard", C.c_int, [C.POINTER(GuardDesc), C.c_void_p]),
     ("uavsal_copy_rows", C.c_int, [C.POINTER(CopyDesc), C.c_void_p]),
+    ("uavsal_fill", C.c_int, [C.POINTER(FillDesc), C.c_void_p]),
+    ("uavsal_plan_add_fill", C.c_int, [C.c_void_p, C.POINTER(FillDesc)]),
     ("uavsal_fused_ir", C.c_int, [C.POINTER(FusedIrDesc), C.c_void_p]),
     ("uavsal_fused_ir_supported", C.c_int, [C.POINTER(FusedIrDesc)]),
     ("uavsal_plan_add_fused_ir", C.c_int, [C.c_void_p, C.POINTER(FusedIrDesc)]),
@@ -198,7 +204,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.uavsal_abi_version() != 18:
+    if lib.uavsal_abi_version() != 19:
         raise RuntimeError("libuavsal_hip.so ABI version mismatch")
     for i, t in enumerate(DESC_TYPES):
         if lib.uavsal_sizeof_desc(i) != C.sizeof(t):

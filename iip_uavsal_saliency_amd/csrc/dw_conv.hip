@@ -150,27 +150,42 @@ __global__ __launch_bounds__(256) void dw3x3_dilated_kernel(const DwK p) {
 // -- twice as slow as d=18).  Stride 1, any dilation.  Thread i handles float4 item i of the slab
 // (pixel = i / (CB/4), channel quad = i % (CB/4)); 256 % (CB/4) == 0, so a thread keeps one channel quad
 // and its taps / BN constants stay in registers.
+// Round 5: (a) the map is staged by LDS-DMA (global_load_lds_dwordx4: a wave request = 1 KB, lane-linear in LDS, which IS the
+// [pixel][channel quad] order of `sm`; no VGPR round trip, every request of the workgroup in flight at once; lanes past the
+// slab / the map fetch a zero page); (b) blocks are renumbered per XCD (xcd_virtual_block): a 16-channel slab reads and
+// writes 64-byte half lines, and the slab holding the other half used to run on ANOTHER XCD (blocks are dealt round-robin),
+// i.e. behind another L2 -- every line was fetched from and written to the memory side twice.  720x1280, 64 frames, 23x40 x
+// 5760 channels (aspp.dw of BASELINE configs[4]): 0.37 of 8 TB/s before (profiles/r4_bench_720p_c4_t16.json).
+__device__ __attribute__((aligned(16))) float g_dw_zero[4];
+
 template <int CB>
 __global__ __launch_bounds__(256) void dw3x3_map_lds_kernel(const DwK p) {
     extern __shared__ __attribute__((aligned(16))) float smap[];
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
     constexpr int Q = CB / 4;
     const int slabs = (p.C4 * 4 + CB - 1) / CB;
-    const int n = blockIdx.x / slabs, c0 = (blockIdx.x - n * slabs) * CB;
+    const int vb = xcd_virtual_block(blockIdx.x, gridDim.x);
+    const int n = vb / slabs, c0 = (vb - n * slabs) * CB;
     const int q = threadIdx.x % Q;
     const int c = c0 + q * 4;
     const bool cok = c < p.C4 * 4;                 // last slab may be narrower
     const int HW = p.H * p.W;
     const float* inb = p.in + (size_t)n * HW * p.ldi + c;
     f32x4* sm = reinterpret_cast<f32x4*>(smap);
-    for (int i = threadIdx.x; i < HW * Q; i += 256) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int i0 = 0; i0 < HW * Q; i0 += 256) {     // (the LDS image is padded to whole 256-item rounds: launch_map_lds)
+        const int i = i0 + threadIdx.x;
         const int pix = i / Q;
-        sm[i] = cok ? ld4(inb + (size_t)pix * p.ldi) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        const float* src = (cok && pix < HW) ? inb + (size_t)pix * p.ldi : g_dw_zero;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smap + (size_t)(i0 + wave * 64) * 4), 16, 0, 0);
     }
     f32x4 wt[9];
     const int cc = cok ? c : 0;
 #pragma unroll
     for (int k = 0; k < 9; ++k) wt[k] = ld4(p.w9c + (size_t)k * (p.C4 * 4) + cc);
     const f32x4 sc = ld4(p.scale + cc), bi = ld4(p.bias + cc);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (!cok) return;
     const int dil = p.dgc ? p.dils[c0 / p.dgc] : p.dil;          // (a slab never straddles two groups: dgc % CB == 0)
@@ -199,10 +214,13 @@ __global__ __launch_bounds__(256) void dw3x3_map_lds_kernel(const DwK p) {
     }
 }
 
+// LDS image of a slab: [pixel][CB / 4] float4 items, padded to whole rounds of 256 items (one LDS-DMA request per wave and round)
+static inline size_t map_lds_bytes(long long px, int cb) { return (size_t)((px * (cb / 4) + 255) / 256 * 256) * 16; }
+
 template <int CB>
 int launch_map_lds(DwK k, hipStream_t s) {
     const int slabs = (k.C4 * 4 + CB - 1) / CB;
-    const size_t smem = (size_t)k.H * k.W * CB * 4;
+    const size_t smem = map_lds_bytes((long long)k.H * k.W, CB);
     hipLaunchKernelGGL((dw3x3_map_lds_kernel<CB>), dim3((unsigned)(k.n_img * slabs)), dim3(256), smem, s, k);
     return uavsal_launch_status();
 }
@@ -210,16 +228,16 @@ int launch_map_lds(DwK k, hipStream_t s) {
 // channel slab width for the whole-map kernel, 0 = the map does not fit 64 KB of LDS at 16 channels
 static inline int map_lds_slab(const DwK& k) {
     const long long px = (long long)k.H * k.W;
-    if (px * 16 * 4 > 65536) return 0;
+    if (map_lds_bytes(px, 16) > 65536) return 0;
     static const int forced = [] { const char* e = getenv("UAVSAL_DW_MAP_CB"); return e ? atoi(e) : 0; }();
-    if ((forced == 16 || forced == 32 || forced == 64) && px * forced * 4 <= 65536) return forced;
+    if ((forced == 16 || forced == 32 || forced == 64) && map_lds_bytes(px, forced) <= 65536) return forced;
     // 32 channels (30 KB of LDS at 12x20: five workgroups per CU cover each other's load / compute phases) where that still
     // gives every CU a workgroup, else 16.  (64-channel slabs, two workgroups per CU: 78.7 vs 51.9 us at 64 x 12x20 x 1920
     // and 15.1 vs 11.0 us at 8 frames -- round 4)
     const int cands[2] = {32, 16};
     for (int i = 0; i < 2; ++i) {
         const int cb = cands[i];
-        if (px * cb * 4 <= 65536 && (long long)k.n_img * ((k.C4 * 4 + cb - 1) / cb) >= 256) return cb;
+        if (map_lds_bytes(px, cb) <= 65536 && (long long)k.n_img * ((k.C4 * 4 + cb - 1) / cb) >= 256) return cb;
     }
     return 16;
 }

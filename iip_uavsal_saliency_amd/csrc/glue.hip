@@ -322,6 +322,22 @@ extern "C" int uavsal_guard(const uavsal_guard_desc* d, uavsal_stream_t stream) 
     return uavsal_launch_status();
 }
 
+// ---------------------------------------------------------------- word fill (see uavsal_hip.h)
+namespace {
+__global__ __launch_bounds__(256) void fill_kernel(const uavsal_fill_desc d) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < d.n; i += (long long)gridDim.x * 256) d.out[i] = d.bits;
+}
+}  // namespace
+
+extern "C" int uavsal_fill(const uavsal_fill_desc* d, uavsal_stream_t stream) {
+    if (!d || !d->out || d->n <= 0) return UAVSAL_EINVAL;
+    if ((uintptr_t)d->out & 3) return UAVSAL_EALIGN;
+    long long nblk = (d->n + 255) / 256;
+    if (nblk > 4096) nblk = 4096;
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, *d);
+    return uavsal_launch_status();
+}
+
 // ---------------------------------------------------------------- strided row copy (see uavsal_hip.h)
 namespace {
 __global__ __launch_bounds__(256) void copy_rows_kernel(const uavsal_copy_desc d) {

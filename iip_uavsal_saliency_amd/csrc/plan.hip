@@ -9,7 +9,7 @@
 
 namespace {
 enum OpKind { OP_CONV = 0, OP_DW, OP_STEM, OP_BILINEAR, OP_TDIFF, OP_TSUM, OP_LAYOUT, OP_GUARD, OP_COPY, OP_FUSED_IR, OP_FORK, OP_JOIN,
-              OP_WINO_IN, OP_WINO_OUT, OP_DW_DOT };
+              OP_WINO_IN, OP_WINO_OUT, OP_DW_DOT, OP_FILL };
 constexpr int MAX_LANES = 8;
 
 // Lanes: lane 0 is the caller's stream; lanes 1..7 are private streams on which independent
@@ -33,6 +33,7 @@ struct Op {
         uavsal_fused_ir_desc fir;
         uavsal_wino_desc wino;
         uavsal_dw_dot_desc dwdot;
+        uavsal_fill_desc fill;
     } u;
 };
 
@@ -51,6 +52,7 @@ int run_op(const Op& op, uavsal_stream_t s) {
         case OP_WINO_IN: return uavsal_wino_input(&op.u.wino, s);
         case OP_WINO_OUT: return uavsal_wino_output(&op.u.wino, s);
         case OP_DW_DOT: return uavsal_dw3x3_dot(&op.u.dwdot, s);
+        case OP_FILL: return uavsal_fill(&op.u.fill, s);
     }
     return UAVSAL_EINVAL;
 }
@@ -181,6 +183,7 @@ UAVSAL_ADD(uavsal_plan_add_fused_ir, OP_FUSED_IR, fir, uavsal_fused_ir_desc)
 UAVSAL_ADD(uavsal_plan_add_wino_input, OP_WINO_IN, wino, uavsal_wino_desc)
 UAVSAL_ADD(uavsal_plan_add_wino_output, OP_WINO_OUT, wino, uavsal_wino_desc)
 UAVSAL_ADD(uavsal_plan_add_dw_dot, OP_DW_DOT, dwdot, uavsal_dw_dot_desc)
+UAVSAL_ADD(uavsal_plan_add_fill, OP_FILL, fill, uavsal_fill_desc)
 
 extern "C" int uavsal_plan_patch_ptr(uavsal_plan* p, int op, int slot, void* ptr) {
     if (!p || op < 0 || op >= (int)p->ops.size() || !ptr) return UAVSAL_EINVAL;
@@ -326,6 +329,7 @@ extern "C" int uavsal_sizeof_desc(int which) {
         case 10: return (int)sizeof(uavsal_fused_ir_desc);
         case 11: return (int)sizeof(uavsal_wino_desc);
         case 12: return (int)sizeof(uavsal_dw_dot_desc);
+        case 13: return (int)sizeof(uavsal_fill_desc);
     }
     return UAVSAL_EINVAL;
 }

@@ -76,6 +76,10 @@ MID_MIN_WGS = int(os.environ.get("UAVSAL_MID_MIN_WGS", "1"))
 MID_MAX_WGS = int(os.environ.get("UAVSAL_MID_MAX_WGS", "288"))
 
 
+# features[14..17] (12x20 maps at 360x640: 12 launches of 6-22 us, none of them a round of the chip) as two half-batch chains on two lanes
+TAIL_SPLIT = os.environ.get("UAVSAL_TAIL_SPLIT", "0") == "1"
+TAIL_SPLIT_FROM = int(os.environ.get("UAVSAL_TAIL_SPLIT_FROM", "14"))
+TAIL_SPLIT_MAX_FRAMES = int(os.environ.get("UAVSAL_TAIL_SPLIT_MAX_FRAMES", "16"))
 PRIORS_OB_LANE = int(os.environ.get("UAVSAL_PRIORS_OB_LANE", "1"))      # 1: both prior nets on lane 1 (two event operations fewer on the main stream: 4.29 -> 4.26 ms at one clip); 2: a lane each
 ASPP_DW_MERGE = os.environ.get("UAVSAL_ASPP_DW_MERGE", "1") == "1"      # 0: the three dilated ASPP depthwise convs as three launches on three lanes
 DW_DOT = os.environ.get("UAVSAL_DW_DOT", "1") == "1"       # 0: the one-channel projection of conv_out_st as a dwproj GEMM + reduce launch
@@ -86,16 +90,73 @@ def _dwproj_patch_waste(h, w):
     return ((h + 7) // 8 * 8) * ((w + 15) // 16 * 16) / float(h * w)
 
 
+ARENA = os.environ.get("UAVSAL_ARENA", "1") == "1"          # 0: one allocation per activation for the life of the plan (rounds 1-4)
+ARENA_ALIGN = 1024                                            # floats (4 KB): every arena buffer starts on a page
+
+
+class _ArenaRef:
+    """An activation's place in the engine's arena: `numel` floats at `off`, live over the recorded ops [first, last]
+    (positions on the main lane's timeline; a use on a side lane counts from that lane's fork to its join).  Stands where a
+    tensor stood in `V.t`, so every view of the buffer shares it; `data_ptr()` refuses to hand out an address outside the
+    live range while a plan is being recorded -- a recorder that forgot to declare a use fails there, at build time."""
+    __slots__ = ("eng", "aid", "numel_", "off", "first", "last", "pinned")
+
+    def __init__(self, eng, aid, numel):
+        self.eng, self.aid, self.numel_ = eng, aid, int(numel)
+        self.off, self.first, self.last, self.pinned = None, None, None, False
+
+    def numel(self):
+        return self.numel_
+
+    def data_ptr(self):
+        e = self.eng
+        if e._dry:
+            return 0
+        if e._recording and not self.pinned and not (self.first <= e._lop <= self.last):
+            raise RuntimeError("arena: %r is addressed by op %d outside its live range [%d, %d] -- a recorder did not declare "
+                               "this use (Engine._touch)" % (self.aid, e._lop, self.first, self.last))
+        return e._arena.data_ptr() + 4 * self.off
+
+    def tensor(self):
+        return self.eng._arena[self.off:self.off + self.numel_]
+
+
+def plan_arena(bufs, align=ARENA_ALIGN):
+    """Offsets for buffers `[(numel, first, last), ...]` such that two buffers whose live ranges intersect never overlap:
+    biggest first, each at the lowest aligned offset free of every already-placed buffer it is live together with.
+    Returns (offsets, total floats, lower bound = the largest sum of simultaneously live sizes)."""
+    order = sorted(range(len(bufs)), key=lambda i: (-bufs[i][0], bufs[i][1]))
+    placed, offs = [], [0] * len(bufs)
+    rnd = lambda n: (n + align - 1) // align * align
+    for i in order:
+        n, f, l = bufs[i]
+        busy = sorted((o, o + rnd(m)) for (o, m, f2, l2) in placed if not (l2 < f or l < f2))
+        at = 0
+        for lo, hi in busy:
+            if at + rnd(n) <= lo:
+                break
+            at = max(at, hi)
+        offs[i] = at
+        placed.append((at, n, f, l))
+    total = max([o + rnd(m) for (o, m, _, _) in placed], default=0)
+    events = sorted(set(f for _, f, _ in bufs))
+    bound = max([sum(rnd(n) for (n, f, l) in bufs if f <= t <= l) for t in events], default=0)
+    return offs, total, bound
+
+
 class Engine:
     def __init__(self, model, device, n_seq, seq_len, H, W, ctx_T, ctx_mode="tile",
                  precision="f32", taps=False, in_dtype=torch.float32, use_graph=False, fuse_dw=None,
                  use_lanes=True, stream_k=True, sync_errors=True, persistent=False,
-                 wcache=None, static_priors=False):
+                 wcache=None, static_priors=False, plan_only=False):
+        """`plan_only`: sizing pass and arena placement only -- no device, nothing allocated, nothing recorded (memory planning
+        questions and the CPU tests of the arena: `arena_stats`, `arena_layout()`)."""
         if precision not in L.PREC:
             raise ValueError("precision must be one of %s" % list(L.PREC))
         self.lib = L.load()
         self.device = torch.device(device)
-        if self.device.type != "cuda":
+        self.plan_only = bool(plan_only)
+        if self.device.type != "cuda" and not self.plan_only:
             raise RuntimeError("Engine needs a cuda (ROCm) device; there is no CPU fallback")
         self.model, self.n_seq, self.seq_len = model, n_seq, seq_len
         self.N = n_seq * seq_len
@@ -176,16 +237,39 @@ class Engine:
         self._scratch: Dict[tuple, torch.Tensor] = {}
         self._lane = 0
         self.plan = None
+        # activation arena (liveness-based): see _buf / _touch / _place_arena
+        self.use_arena = ARENA and bool(getattr(model, "arena", True))
+        self.arena_debug = bool(getattr(model, "arena_debug", False)) or os.environ.get("UAVSAL_ARENA_DEBUG", "0") == "1"
+        self._refs: Dict[object, _ArenaRef] = {}
+        self._arena = None
+        self._recording = False
+        self._lop = -1                        # logical op index (poison fills of the debug mode do not count)
+        self._lane_open: Dict[int, int] = {}
+        self._lane_refs: Dict[int, set] = {}
+        self._scr_serial = 0
+        self.arena_stats: Dict[str, float] = {}
         # everything below allocates on, or creates native objects for, the CURRENT device (the plan's error word, its
         # `done` event, workspaces, occupancy queries): make that the engine's device, whatever the caller's is
+        if self.plan_only:
+            self._dry = self._recording = True
+            self._build()
+            self._close_lanes()
+            if self.use_arena:
+                self._place_arena()
+            return
         with torch.cuda.device(self.device):
             self._init_on_device(use_lanes)
 
-    def _init_on_device(self, use_lanes):
-        # pass 1 sizes the shared scratch, pass 2 records the launches
-        self._dry = True
-        self._build()
+    def _init_on_device(self, use_lanes, resume=False):
+        # pass 1 sizes the shared scratch and the arena, pass 2 records the launches (`resume`: pass 1 already ran -- plan_only)
+        if not resume:
+            self._dry = True
+            self._recording = True
+            self._build()
+            self._close_lanes()
         self._split_want -= self._no_shadow
+        if self.use_arena and (not resume or self._arena is None):
+            self._place_arena()
         for k, need in self._scratch_need.items():
             # (the Winograd V planes are zero-filled once: their padding rows are multiplied by the GEMM, never read back)
             alloc = torch.zeros if k[0] == "WV" else torch.empty
@@ -193,42 +277,139 @@ class Engine:
                                      device=self.device)
         self._lane = 0
         self._dry = False
+        self._lop, self._scr_serial, self._lane_open, self._lane_refs = -1, 0, {}, {}
+        self._poison_done = set()
         self.ops_meta, self.stage_ranges, self.named, self._op_idx = [], {}, {}, {}
         self.plan = C.c_void_p(self.lib.uavsal_plan_create())
         if not self.plan:
             raise RuntimeError("uavsal_plan_create failed")
         self._err = self.lib.uavsal_plan_error_word(self.plan)
         self._build()
+        self._flush_poison(final=True)
+        self._recording = False
         self.use_lanes = bool(use_lanes)
         L.check(self.lib.uavsal_plan_enable_lanes(self.plan, 1 if self.use_lanes else 0), "plan_enable_lanes")
         self._graph_ready = False
 
     def __del__(self):
         try:
-            if getattr(self, "plan", None):
+            if getattr(self, "plan", None) and not getattr(self, "plan_only", False):
                 self.lib.uavsal_plan_destroy(self.plan)
                 self.plan = None
         except Exception:
             pass
 
     # ------------------------------------------------------------------ memory helpers
-    def _buf(self, name, n, h, w, c) -> V:
+    def _buf(self, name, n, h, w, c, pinned=False) -> V:
+        """A named NHWC activation.  With the arena (default) it is `n*h*w*c` floats of ONE pool, placed so that it shares
+        addresses only with buffers it is never live together with (first declared use .. last declared use of the recorded
+        plan); `pinned`: survives the call (the resident recurrent state), its own allocation."""
         sp = None
-        if self._dry:
+        numel = n * h * w * c
+        if self.use_arena and not pinned:
+            t = self._ref(name, numel)
+        elif self._dry:
             t = _Fake()
         else:
-            t = torch.empty(n * h * w * c, dtype=torch.float32, device=self.device)
+            t = torch.empty(numel, dtype=torch.float32, device=self.device)
             self._keep.append(t)
-            if name in self._split_want and c % 32 == 0:
-                # NaN-filled, not empty: if a producer that cannot write shadows were ever added without entering
-                # its output in `_no_shadow`, the GEMM reading this shadow would multiply NaNs -- the first run of the
-                # plan then fails loudly (run(): `_verify_first_run`) instead of returning plausible wrong maps
-                sp = torch.full((2 * n * h * w * c,), float("nan"), dtype=torch.float16, device=self.device)
-                self._keep.append(sp)
+        if not self._dry and name in self._split_want and c % 32 == 0:
+            # NaN-filled, not empty: if a producer that cannot write shadows were ever added without entering
+            # its output in `_no_shadow`, the GEMM reading this shadow would multiply NaNs -- the first run of the
+            # plan then fails loudly (run(): `_verify_first_run`) instead of returning plausible wrong maps.
+            # (Shadows stay outside the arena for that reason: a recycled range would hold somebody's finite data)
+            sp = torch.full((2 * numel,), float("nan"), dtype=torch.float16, device=self.device)
+            self._keep.append(sp)
         v = V(t, n, h, w, c, sp=sp, key=name)
         if name:
             self.named[name] = v
         return v
+
+    # ---- activation arena -------------------------------------------------------------------------------------------
+    def _ref(self, aid, numel) -> _ArenaRef:
+        if self._dry:
+            if aid in self._refs:
+                raise RuntimeError("arena: buffer %r declared twice" % (aid,))
+            r = self._refs[aid] = _ArenaRef(self, aid, numel)
+            return r
+        r = self._refs.get(aid)
+        if r is None or r.numel_ != int(numel):
+            raise RuntimeError("arena: buffer %r of the recording pass was not (or differently) declared in the sizing pass" % (aid,))
+        return r
+
+    def _touch(self, *vs):
+        """Declare that the op being recorded (the last `_meta`) reads or writes these views.  Sizing pass: grows the live
+        range of their arena buffers -- on a side lane from the lane's fork (it may start right there) to, at its join, the
+        join (it may still be running until then)."""
+        if not self._dry:
+            return
+        for v in vs:
+            r = getattr(v, "t", None) if v is not None else None
+            if not isinstance(r, _ArenaRef):
+                continue
+            lo = hi = self._lop
+            if self._lane != 0:
+                lo = self._lane_open.get(self._lane, lo)
+                self._lane_refs.setdefault(self._lane, set()).add(r)
+            r.first = lo if r.first is None else min(r.first, lo)
+            r.last = hi if r.last is None else max(r.last, hi)
+
+    def _close_lanes(self):
+        for lane in list(self._lane_refs):          # (a lane the plan never joined: live to the end)
+            for r in self._lane_refs.pop(lane):
+                r.last = max(r.last, len(self.ops_meta))
+        self._lane_open = {}
+
+    TAP_NAMES = ("c3", "c4", "c5", "sfnet", "st0", "st1", "fust_in_cb", "prefuse", "rnn")
+
+    def _place_arena(self):
+        refs = list(self._refs.values())
+        last_op = len(self.ops_meta)
+        for r in refs:
+            if r.first is None:                      # declared, never used by an op: keep it addressable for the whole plan
+                r.first, r.last = 0, last_op
+        if self.keep_taps:                           # read back after the run (Engine.tap)
+            for k in self.TAP_NAMES:
+                v = self.named.get(k)
+                if v is not None and isinstance(v.t, _ArenaRef):
+                    v.t.last = last_op
+        offs, total, bound = plan_arena([(r.numel_, r.first, r.last) for r in refs])
+        for r, o in zip(refs, offs):
+            r.off = o
+        self.arena_stats = {"arena_mb": total * 4 / 1e6, "live_bound_mb": bound * 4 / 1e6,
+                            "unshared_mb": sum(r.numel_ for r in refs) * 4 / 1e6, "buffers": len(refs)}
+        if self.plan_only:
+            return
+        self._arena = torch.empty(max(total, 4), dtype=torch.float32, device=self.device)
+        if self.arena_debug:
+            self._arena.fill_(float("nan"))
+
+    def arena_layout(self):
+        """[(buffer id, offset, floats, first op, last op)] of the activation arena, by offset."""
+        return sorted(((r.aid, r.off, r.numel_, r.first, r.last) for r in self._refs.values()), key=lambda t: (t[1], t[3]))
+
+    def _flush_poison(self, final=False):
+        """Debug mode: once the op that ends a buffer's live range has been recorded -- and before anything of the next op,
+        a fork included -- the range is filled with NaN on the main lane, so a use after release cannot go unnoticed."""
+        if not (self.arena_debug and self.use_arena) or self._dry:
+            return
+        due = [r for r in self._refs.values() if r not in self._poison_done and not r.pinned
+               and (final or r.last < self._lop + 1)]
+        if not due:
+            return
+        if self._lane != 0:
+            L.check(self.lib.uavsal_plan_set_lane(self.plan, 0), "plan_set_lane")
+        for r in sorted(due, key=lambda r_: r_.off):
+            self._poison_done.add(r)
+            if final and r.last >= self._lop:        # still live at the end of the plan (taps, the history the state is read from)
+                continue
+            self._op_idx["poison:%s" % (r.aid,)] = len(self.ops_meta)
+            self.ops_meta.append(dict(kind="poison", name="poison:%s" % (r.aid,), flops=0.0, bytes=4.0 * r.numel_))
+            d = L.FillDesc()
+            d.out, d.n, d.bits = self._arena.data_ptr() + 4 * r.off, r.numel_, 0x7FC00000
+            self._add(self.lib.uavsal_plan_add_fill, d, "plan_add_fill")
+        if self._lane != 0:
+            L.check(self.lib.uavsal_plan_set_lane(self.plan, self._lane), "plan_set_lane")
 
     def _scr_split(self, n, h, w, c) -> V:
         """A depthwise output that exists only as its split shadow (scratch, per lane)."""
@@ -256,9 +437,13 @@ class Engine:
         return int(self.lib.uavsal_conv_uses_split(C.byref(d))) == 1
 
     def _scr(self, kind, n, h, w, c) -> V:
-        """Scratch for the expanded tensors of an inverted-residual block, one pool per (kind, lane):
-        blocks on the same lane run back to back and share it, concurrent lanes never do."""
+        """Scratch for the expanded tensors of an inverted-residual block and the Winograd planes.  With the arena: an
+        anonymous buffer of the pool, live from its producer to its last reader (blocks that run back to back end up on the
+        same addresses, concurrent lanes never do).  Without: one pool per (kind, lane)."""
         numel = n * h * w * c
+        if self.use_arena:
+            self._scr_serial += 1
+            return V(self._ref((kind, self._scr_serial), numel), n, h, w, c)
         key = (kind, self._lane)
         if self._dry:
             self._scratch_need[key] = max(self._scratch_need.get(key, 0), numel)
@@ -270,6 +455,7 @@ class Engine:
         """Following ops (until `main()`) go to `lane`, which starts after everything recorded on
         lane 0 so far."""
         self._meta(kind="sync", name="fork%d" % lane, flops=0.0, bytes=0.0)
+        self._lane_open.setdefault(lane, self._lop)
         if not self._dry:
             r = self.lib.uavsal_plan_add_fork(self.plan, lane)
             if r < 0:
@@ -284,6 +470,9 @@ class Engine:
 
     def join(self, lane):
         self._meta(kind="sync", name="join%d" % lane, flops=0.0, bytes=0.0)
+        for r_ in self._lane_refs.pop(lane, ()):          # what ran on the lane may have been running until here
+            r_.last = max(r_.last, self._lop)
+        self._lane_open.pop(lane, None)
         if not self._dry:
             r = self.lib.uavsal_plan_add_join(self.plan, lane)
             if r < 0:
@@ -343,6 +532,8 @@ class Engine:
 
     # ------------------------------------------------------------------ op recorders
     def _meta(self, **kw):
+        self._flush_poison()
+        self._lop += 1
         self._op_idx[kw.get("name")] = len(self.ops_meta)       # == index of the op in the native plan
         self.ops_meta.append(kw)
 
@@ -375,6 +566,7 @@ class Engine:
             byts = 4.0 * n_img * (hin * win * cin + hw * cout) + 4.0 * cin * (cout + 11)
         self._meta(kind="conv%d" % (3 if taps == 9 else 1), name=name, flops=flops, bytes=byts,
                    M=n_img * hw, K=cin * taps, Nc=cout)
+        self._touch(a, out, res, aux, out2)
         # split shadows (f16x3): can this launch write one for its output / read its input pre-split?
         shadow_out = False
         if self.split_mode:
@@ -476,6 +668,7 @@ class Engine:
         v = self._scr("WV", pp, mp, 1, cin)
         mm = self._scr("WM", pp, mp, 1, cout)
         self._meta(kind="wino_in", name=name + ".xin", flops=0.0, bytes=4.0 * (n * hw * cin + float(pp) * tiles * cin))
+        self._touch(a, v)
         if not self._dry:
             wi = L.WinoDesc()
             wi.inp, wi.ldi, wi.in_img_stride = a.ptr, a.ld, st.get("a", hw)
@@ -485,6 +678,7 @@ class Engine:
         self._meta(kind="conv1", name=name, flops=2.0 * pp * tiles * cin * cout,
                    bytes=4.0 * pp * (tiles * (cin + cout) + cin * cout), M=pp * mp, K=cin, Nc=cout,
                    direct_flops=2.0 * n * hw * cin * cout * 9)
+        self._touch(v, mm)
         if not self._dry:
             key = ("wino", id(conv), wslice, r)
             if key not in self._wcache:
@@ -505,6 +699,7 @@ class Engine:
             self.ops_meta[-1]["dwproj"] = 0
             self._add(self.lib.uavsal_plan_add_conv, d, "plan_add_conv(%s)" % name)
         self._meta(kind="wino_out", name=name + ".xout", flops=0.0, bytes=4.0 * (float(pp) * tiles * cout + n * hw * cout))
+        self._touch(mm, out, a, *(twa or ()))
         if out.key is not None and self._dry:
             self._no_shadow.add(out.key)            # the output transform does not write split shadows
         if not self._dry:
@@ -530,6 +725,7 @@ class Engine:
         byts = 4.0 * a.n * c * (a.h * a.w + ho * wo) + 4.0 * 9 * c + 4.0 * 2 * c
         self._meta(kind="dw", name=name, flops=2.0 * 9 * a.n * ho * wo * c, bytes=byts, stride=stride,
                    dil=dilation if not isinstance(dilation, (list, tuple)) else tuple(dilation), patches44=a.n * ((ho + 3) // 4) * ((wo + 3) // 4) * (c // 4))
+        self._touch(a, out)
         if self._dry:
             return
         grouped = isinstance(conv, (list, tuple))      # several dilated branches of one map: channel groups with their own dilation
@@ -568,6 +764,7 @@ class Engine:
         c = a.c
         self._meta(kind="dw_dot", name=name, flops=2.0 * 10 * a.n * a.h * a.w * c, bytes=4.0 * a.n * a.h * a.w * (c + 1) + 4.0 * 12 * c,
                    stride=1, dil=1, kernel="dw3x3_dot_kernel<4, 4>")
+        self._touch(a, out)
         if self._dry:
             return
         key = ("dwdot", id(dwc), id(pl))
@@ -586,6 +783,7 @@ class Engine:
 
     def bilinear(self, name, a: V, out: V, src_mod=None, src_div=1):
         self._meta(kind="bilinear", name=name, flops=0.0, bytes=4.0 * out.n * out.h * out.w * out.c * 2)
+        self._touch(a, out)
         if self._dry:
             return
         d = L.BilinearDesc()
@@ -597,11 +795,15 @@ class Engine:
         d.src_mod, d.src_div = (out.n if src_mod is None else src_mod), src_div
         self._add(self.lib.uavsal_plan_add_bilinear, d, "plan_add_bilinear(%s)" % name)
 
-    def layout(self, name, src_ptr, dst_ptr, n, c, hw, ld, to_nhwc, cpad=0):
+    def layout(self, name, src, dst, n, c, hw, ld, to_nhwc, cpad=0):
+        """`src` / `dst`: a view (its address is taken once the op is open, so that the arena sees the use at this op) or a raw
+        device address (the caller's boundary tensors)."""
         self._meta(kind="layout", name=name, flops=0.0, bytes=8.0 * n * c * hw)
+        self._touch(*(t for t in (src, dst) if isinstance(t, V)))
         if self._dry:
             return
         d = L.LayoutDesc()
+        src_ptr, dst_ptr = (t.ptr if isinstance(t, V) else t for t in (src, dst))
         d.inp, d.out, d.n_img, d.C, d.HW, d.ld, d.to_nhwc, d.Cpad = src_ptr, dst_ptr, n, c, hw, ld, to_nhwc, cpad
         self._add(self.lib.uavsal_plan_add_layout, d, "plan_add_layout(%s)" % name)
 
@@ -632,6 +834,7 @@ class Engine:
                    bytes=4.0 * x.n * (x.h * x.w * x.c + ho * wo * out.c * (2 if blk.use_res_connect else 1)),
                    unfused_bytes=4.0 * x.n * (x.h * x.w * (x.c + (2 * blk.hidden if blk.expand_ratio != 1 else 0))
                                               + ho * wo * (2 * blk.hidden + out.c)))
+        self._touch(x, out)
         if out.key is not None:
             self._no_shadow.add(out.key)            # this kernel does not write split shadows
         if self._dry:
@@ -732,12 +935,12 @@ class Engine:
 
         # ---- boundary: state and priors NCHW -> NHWC
         s0 = len(self.ops_meta)
-        h0 = self._buf("h0", self.n_seq, h, w, 256)
+        h0 = self._buf("h0", self.n_seq, h, w, 256, pinned=self.persistent)
         # buffers written by kernels that do not produce split shadows
         self._no_shadow.update(("h0", "c0", "gauss_in", "ob_in", "f0", "ctx_sum", "lstm_pre", "lstm_c", "twa_pre"))
         self._no_shadow.update("st%d_dif" % i for i in range(len(m.st_layer)))
         lstm_model = getattr(m, "rnn_type", "twa") == "lstm"
-        c0 = self._buf("c0", self.n_seq, h, w, 256) if lstm_model else None
+        c0 = self._buf("c0", self.n_seq, h, w, 256, pinned=self.persistent) if lstm_model else None
         Np = 1 if self.static_priors else N
         # which priors this model has (reference model.py:281-324: a disabled prior has no net, and with none at all the two
         # fusion blocks do not exist either); enabled priors keep the reference's concat order gauss | observed | context
@@ -753,10 +956,7 @@ class Engine:
         if not self.persistent:          # persistent mode: h0 / c0 ARE the state, staged only on demand (run())
             names = ["state.in"] + (["cstate.in"] if lstm_model else [])
             for nm, src, dst in zip(names, ("state_in", "cstate_in"), (h0, c0)):
-                if self._dry:
-                    self._meta(kind="layout", name=nm, flops=0.0, bytes=8.0 * self.n_seq * 256 * hw)
-                else:
-                    self.layout(nm, getattr(self, src).data_ptr(), dst.ptr, self.n_seq, 256, hw, 256, 1)
+                self.layout(nm, None if self._dry else getattr(self, src).data_ptr(), dst, self.n_seq, 256, hw, 256, 1)
         self._mark("boundary_in", s0)
 
         # ---- backbone: MobileNetV2 features[0:18] (model_feature.py:62-69)
@@ -765,6 +965,7 @@ class Engine:
         x = self._buf("f0", N, H1, W1, 32)
         self._meta(kind="stem", name="features.0", flops=2.0 * 27 * 32 * N * H1 * W1,
                    bytes=(4.0 if self.in_dtype == torch.float32 else 1.0) * N * 3 * self.H * self.W + 4.0 * N * H1 * W1 * 32)
+        self._touch(x)
         if not self._dry:
             conv0, bn0 = feats[0][0], feats[0][1]
             key = ("stem", id(conv0))
@@ -789,6 +990,8 @@ class Engine:
         # chip each: up to two clips of 8 frames; 4.26 -> 4.25 ms at one clip), beside features.5-10 from there on (8 clips: 27.92
         # vs 27.97 ms).  A function of the frame count only
         priors_at = int(os.environ.get("UAVSAL_PRIORS_AT", "11" if N <= 16 else "5"))
+        tail_halves = TAIL_SPLIT and N >= 2 and N <= TAIL_SPLIT_MAX_FRAMES
+        tail_chain = []
         for i in range(1, 18):
             if i == priors_at:
                 self._mark("backbone.0-%d" % (priors_at - 1), s0)
@@ -816,10 +1019,7 @@ class Engine:
                     else:
                         L.check(self.lib.uavsal_plan_set_lane(self.plan, lane), "plan_set_lane") if not self._dry else None
                         self._lane = lane
-                    if self._dry:
-                        self._meta(kind="layout", name=nm + ".in", flops=0.0, bytes=8.0 * Np * c * hw)
-                    else:
-                        self.layout(nm + ".in", getattr(self, src).data_ptr(), dst.ptr, Np, c, hw, c, 1)
+                    self.layout(nm + ".in", None if self._dry else getattr(self, src).data_ptr(), dst, Np, c, hw, c, 1)
                     self.ir_block(nm + ".0", dst, blocks[0], mid)
                     self.ir_block(nm + ".1", mid, blocks[1], cbs.slice(sl, 64))
                     if self.static_priors:      # frame 0 of the net's output -> every frame (same-size resize: an exact copy)
@@ -831,9 +1031,23 @@ class Engine:
             blk = feats[i]
             ho, wo = (x.h - 1) // blk.stride + 1, (x.w - 1) // blk.stride + 1
             y = self._buf("f%d" % i, N, ho, wo, blk.cout)
-            self.ir_block("features.%d" % i, x, blk, y)
+            if tail_halves and i >= TAIL_SPLIT_FROM:
+                # latency-bound launches on the 1/32-scale map (each far below one round of the chip): the two halves of the
+                # frames run as two independent chains, the first on lane 2, the second here (blocks are per-frame arithmetic)
+                tail_chain.append((i, x, blk, y))
+            else:
+                self.ir_block("features.%d" % i, x, blk, y)
             x = y
             tapsrc[i] = y
+        if tail_chain:
+            n0 = N // 2
+            self.fork(2)
+            for (i, xi, blk, yi) in tail_chain:
+                self.ir_block("features.%d/a" % i, xi.frames(0, n0), blk, yi.frames(0, n0))
+            self.main()
+            for (i, xi, blk, yi) in tail_chain:
+                self.ir_block("features.%d/b" % i, xi.frames(n0, N - n0), blk, yi.frames(n0, N - n0))
+            self.join(2)
         c3, c4, c5 = tapsrc[6], tapsrc[13], tapsrc[17]
         self.named.update(c3=c3, c4=c4, c5=c5)
         self._mark("backbone.%d-17" % priors_at, s0)
@@ -929,6 +1143,7 @@ class Engine:
                 self.fork(6)
             self.conv("st%d.reduce" % i, x, te.reduce_conv[0], te.reduce_conv[1], r, R6)
             self._meta(kind="tdiff", name="st%d.tdiff" % i, flops=0.0, bytes=4.0 * N * hw * 96)
+            self._touch(r, dif)
             if not self._dry:
                 d = L.TdiffDesc()
                 d.inp, d.ldi, d.out, d.ldo = r.ptr, 32, dif.ptr, 64
@@ -962,6 +1177,7 @@ class Engine:
                 B = N // self.ctx_T
                 tsum = self._buf("ctx_sum", B, h, w, 256)
                 self._meta(kind="tsum", name="ctx.sum", flops=0.0, bytes=4.0 * (N + B) * hw * 256)
+                self._touch(xs, tsum)
                 if not self._dry:
                     d = L.TsumDesc()
                     d.inp, d.ldi, d.out, d.ldo = xs.ptr, 320, tsum.ptr, 256
@@ -1043,6 +1259,7 @@ class Engine:
             # h_last of every clip (NHWC rows of the history) -> the resident state buffer, one strided copy
             for hist, _, keep in outs:
                 self._meta(kind="copy", name="state.keep", flops=0.0, bytes=8.0 * self.n_seq * 256 * hw)
+                self._touch(hist, keep)
                 if not self._dry:
                     d = L.CopyDesc()
                     d.inp, d.out = hist.frames(Lq - 1, 1).ptr, keep.ptr
@@ -1053,12 +1270,11 @@ class Engine:
                 for hist, dst, _ in outs:
                     last = hist.frames(c * Lq + Lq - 1, 1)
                     nm = "%s%d" % (dst.replace("_", "."), c)           # state.out0, cstate.out0, ...
-                    if self._dry:
-                        self._meta(kind="layout", name=nm, flops=0.0, bytes=8.0 * 256 * hw)
-                    else:
-                        self.layout(nm, last.ptr, getattr(self, dst).data_ptr() + 4 * c * 256 * hw, 1, 256, hw, 256, 0)
+                    self.layout(nm, last, None if self._dry else getattr(self, dst).data_ptr() + 4 * c * 256 * hw, 1, 256, hw, 256, 0)
         # error guard: poisons what the caller will see if any kernel of this run set the error word
         self._meta(kind="guard", name="guard", flops=0.0, bytes=0.0)
+        if self.persistent:
+            self._touch(h0, c0)
         if not self._dry:
             bufs = [(self.out.data_ptr(), self.out.numel())]
             if self.persistent:
@@ -1247,10 +1463,17 @@ class Engine:
     def tap(self, name) -> torch.Tensor:
         """NCHW copy of a named NHWC buffer (debug / parity tests)."""
         v = self.named[name]
-        t = v.t.view(v.n, v.h, v.w, v.ld) if v.t.numel() == v.n * v.h * v.w * v.ld else None
+        base = v.t.tensor() if isinstance(v.t, _ArenaRef) else v.t
+        t = base.view(v.n, v.h, v.w, v.ld) if base.numel() == v.n * v.h * v.w * v.ld else None
         if t is None:
             raise RuntimeError("tap %s is not a dense buffer" % name)
         return t[..., v.coff:v.coff + v.c].permute(0, 3, 1, 2).contiguous()
+
+    def run_ops(self, first, last):
+        """Launch ops [first, last) once, flat on the current stream (no lanes, no staging): puts the activations an op reads
+        back in place before it is timed by itself -- buffers share addresses by liveness."""
+        if last > first:
+            L.check(self.lib.uavsal_plan_run(self.plan, first, last, self._stream()), "plan_run")
 
     def time_ops(self, first, last, iters=10) -> float:
         """Average device milliseconds for ops [first,last) measured with hipEvents on the launch stream."""

@@ -194,6 +194,13 @@ class UAVSal(nn.Module):
         # reference's caller repeats one prior file over all frames, utils_data.py:466-467, 601-602): the two prior nets run on
         # one frame instead of on every frame.  Decided from the strides, never from the values; False: always per frame.
         self.dedupe_priors = True
+        # Activations of a plan live in ONE arena per plan, placed by liveness (first / last use over the recorded launches; a
+        # use on a side lane counts from the lane's fork to its join): memory per call follows the largest set of tensors that
+        # is live at once, not the number of layers (720x1280, 4 x 16 frames: 14.7 GB instead of 42.6).  False: one allocation
+        # per activation for the life of the plan (rounds 1-4).  `arena_debug`: every range is NaN-filled right after its last
+        # declared use, so that a use after release shows up as NaN maps (tests).
+        self.arena = True
+        self.arena_debug = False
         self.max_engines = 4            # launch plans kept per model (LRU); packed weights are shared by all
         self.check_weight_versions = True   # rebuild plans when a parameter/buffer was modified in place
         self.sfnet = uavsal_srfnet_aspp(cnn_type, last_channel=planes)
@@ -299,7 +306,8 @@ class UAVSal(nn.Module):
                ctx_mode, self.precision, bool(taps), in_dtype, bool(self.use_graph), self.rnn_type, self.fuse_dw, bool(self.use_lanes),
                bool(self.stream_k), bool(self.persistent_state), tuple(getattr(self, "_sk_debug", (0, 0))),
                self.presplit, bool(self.fuse_blocks), bool(getattr(self, "winograd", True)), getattr(self, "winograd_r", None),
-               tuple(sorted((getattr(self, "prec_overrides", None) or {}).items())), bool(static_priors))
+               tuple(sorted((getattr(self, "prec_overrides", None) or {}).items())), bool(static_priors),
+               bool(getattr(self, "arena", True)), bool(getattr(self, "arena_debug", False)))
         eng = self._engines.get(key)
         if eng is None:
             while len(self._engines) >= max(1, int(self.max_engines)):

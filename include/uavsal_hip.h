@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define UAVSAL_ABI_VERSION 18
+#define UAVSAL_ABI_VERSION 19
 
 /* argument errors */
 #define UAVSAL_EINVAL   (-1)  /* null pointer / non-positive size */
@@ -409,6 +409,18 @@ typedef struct uavsal_copy_desc {
 int uavsal_copy_rows(const uavsal_copy_desc* d, uavsal_stream_t stream);
 
 /*
+ * Fill `n` 32-bit words at `out` with the bit pattern `bits`.  The activation arena's debug mode records one after
+ * the last reader of every buffer (bits = a quiet NaN), so that a kernel that still reads a released range -- or a
+ * later buffer placed over a live one -- shows up as NaN in the maps instead of as a plausible number
+ * (the reference keeps O(group) memory per call, Demo_Test.py:75-86; here liveness does: engine.py).
+ */
+typedef struct uavsal_fill_desc {
+    uint32_t* out;  int64_t n;  uint32_t bits;
+} uavsal_fill_desc;
+
+int uavsal_fill(const uavsal_fill_desc* d, uavsal_stream_t stream);
+
+/*
  * Error guard: the last launch of a forward.  If `*err` is non-zero (a kernel of this run reported
  * UAVSAL_ERR_*), every listed buffer is overwritten with NaN, so that no caller can mistake the result
  * for a saliency map; `*err` is then copied to `*host_err` (a device-visible host word, may be NULL).
@@ -439,6 +451,7 @@ int uavsal_plan_add_tsum(uavsal_plan* p, const uavsal_tsum_desc* d);
 int uavsal_plan_add_layout(uavsal_plan* p, const uavsal_layout_desc* d);
 int uavsal_plan_add_copy(uavsal_plan* p, const uavsal_copy_desc* d);
 int uavsal_plan_add_fused_ir(uavsal_plan* p, const uavsal_fused_ir_desc* d);
+int uavsal_plan_add_fill(uavsal_plan* p, const uavsal_fill_desc* d);
 /* The plan owns one device error word (for uavsal_conv_desc.err of its convs) and a host mirror of it.
  * add_guard records a uavsal_guard over up to three output buffers with those words filled in. */
 int32_t* uavsal_plan_error_word(uavsal_plan* p);
@@ -476,7 +489,7 @@ int uavsal_plan_graph_launch(uavsal_plan* p, uavsal_stream_t stream);
 int uavsal_plan_time(uavsal_plan* p, int first, int last, int iters, uavsal_stream_t stream, float* ms);
 
 int uavsal_abi_version(void);
-int uavsal_sizeof_desc(int which); /* 0 conv,1 dw,2 stem,3 bilinear,4 tdiff,5 tsum,6 layout,7 post,8 guard,9 copy,10 fused_ir,11 wino */
+int uavsal_sizeof_desc(int which); /* 0 conv,1 dw,2 stem,3 bilinear,4 tdiff,5 tsum,6 layout,7 post,8 guard,9 copy,10 fused_ir,11 wino,12 dw_dot,13 fill */
 const char* uavsal_build_info(void);
 
 #ifdef __cplusplus

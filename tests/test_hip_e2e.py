@@ -303,6 +303,51 @@ def test_forward_clips_vs_reference_golden(hip_model, golden_dir, name, prec):
     hip_model.invalidate_engines()          # the 720p plan holds ~20 GB of activations: release it
 
 
+@pytest.mark.parametrize("prec", PARITY_PRECS)
+@pytest.mark.parametrize("shape", [(1, 4, 96, 160), (2, 4, 96, 160), (4, 3, 72, 104), (1, 8, 360, 640)])
+def test_arena_is_bit_identical_and_never_reads_a_released_range(hip_model, prec, shape):
+    """The activation arena (engine.py: one pool per plan, placed by liveness) against one allocation per activation: the
+    same launches on other addresses, so maps and states are identical BIT FOR BIT -- and again with `arena_debug`, where
+    every range is NaN-filled right after its last declared use (a use after release, or a buffer placed over a live one,
+    cannot stay finite); taps included (they pin their buffers to the end of the plan); persistent state; two calls."""
+    C, T, H, W = shape
+    calls = [make_clips(C, T, H, W, 0, t0=k * T) for k in range(2)]
+    calls = [(x.cuda(), [cb[0].cuda(), cb[1].cuda()]) for x, cb in calls]
+    hip_model.precision = prec
+    res = {}
+    try:
+        for mode in ("unshared", "arena", "debug", "debug+persistent"):
+            hip_model.arena = mode != "unshared"
+            hip_model.arena_debug = mode.startswith("debug")
+            hip_model.persistent_state = mode.endswith("persistent")
+            st, outs = None, []
+            for x, cb in calls:
+                taps = {} if mode == "debug" else None
+                o, st = hip_model.forward_clips(x, cb, st.detach() if st is not None else None, taps)
+                outs.append((o.clone(), st.clone()))
+                if taps is not None:
+                    assert all(bool(torch.isfinite(t).all().item()) for t in taps.values())
+            res[mode] = outs
+            eng = list(hip_model._engines.values())[-1]
+            assert eng.use_arena == (mode != "unshared")
+            if mode.startswith("debug"):
+                assert any(o["kind"] == "poison" for o in eng.ops_meta)
+                # (with taps the buffers the test reads back are pinned to the end of the plan; the rest is poisoned)
+            if mode == "arena":
+                st_ = eng.arena_stats
+                print("arena %s %s: %.1f MB (live bound %.1f, unshared %.1f)" % (shape, prec, st_["arena_mb"], st_["live_bound_mb"], st_["unshared_mb"]))
+                assert st_["arena_mb"] < 0.45 * st_["unshared_mb"]
+        for mode in ("arena", "debug", "debug+persistent"):
+            for k in range(2):
+                assert bool(torch.isfinite(res[mode][k][0]).all().item()), (mode, k)
+                assert torch.equal(res[mode][k][0], res["unshared"][k][0]), (mode, k, (res[mode][k][0] - res["unshared"][k][0]).abs().max().item())
+                assert torch.equal(res[mode][k][1], res["unshared"][k][1]), (mode, k)
+    finally:
+        hip_model.arena, hip_model.arena_debug, hip_model.persistent_state = True, False, False
+        if H >= 360:
+            hip_model.invalidate_engines()
+
+
 def test_persistent_state_equals_refed_state(hip_model):
     """Opt-in persistent-state mode (BASELINE configs[4], SURVEY.md 8(b) Ownership): the state stays in the
     engine's NHWC buffer between calls == re-feeding the returned state, bit for bit; a foreign tensor is

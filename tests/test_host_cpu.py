@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert declared == bound, (declared ^ bound)
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.uavsal_abi_version() == 18
+    assert lib.uavsal_abi_version() == 19
     assert b"gfx950" in lib.uavsal_build_info()
 
 
@@ -343,6 +343,111 @@ def test_every_bias_type_builds_the_reference_module_tree():
         UAVSal(bias_type=[1, 1])
 
 
+def test_arena_planner_never_overlaps_live_buffers():
+    """`engine.plan_arena`: buffers whose live ranges intersect get disjoint address ranges, the total stays near the
+    largest simultaneously-live set, and disjoint lifetimes DO share (random instances + the degenerate ones)."""
+    from iip_uavsal_saliency_amd.engine import plan_arena, ARENA_ALIGN
+    rng = np.random.default_rng(7)
+    rnd = lambda n: (n + ARENA_ALIGN - 1) // ARENA_ALIGN * ARENA_ALIGN
+    for trial in range(40):
+        n = int(rng.integers(1, 60))
+        bufs = []
+        for _ in range(n):
+            f = int(rng.integers(0, 100))
+            bufs.append((int(rng.integers(1, 5_000_000)), f, f + int(rng.integers(0, 30))))
+        offs, total, bound = plan_arena(bufs)
+        for i in range(n):
+            assert offs[i] % ARENA_ALIGN == 0 and offs[i] + bufs[i][0] <= total
+            for j in range(i):
+                if not (bufs[i][2] < bufs[j][1] or bufs[j][2] < bufs[i][1]):       # live together
+                    assert offs[i] + rnd(bufs[i][0]) <= offs[j] or offs[j] + rnd(bufs[j][0]) <= offs[i], (trial, i, j)
+        assert bound <= total <= sum(rnd(b[0]) for b in bufs)
+        assert total <= 1.6 * bound + ARENA_ALIGN, (trial, total, bound)          # (greedy-by-size: never far from the bound)
+    # a chain of equal buffers, each live together with its neighbour only: two slots
+    chain = [(1000, i, i + 1) for i in range(10)]
+    offs, total, bound = plan_arena(chain)
+    assert total == 2 * rnd(1000) == bound and len(set(offs)) == 2
+    assert plan_arena([]) == ([], 0, 0)
+
+
+def test_arena_layout_of_the_real_plans():
+    """The sizing pass of the real launch plans on CPU (`plan_only`): every pair of activations that is live together is
+    disjoint in the arena; a side lane's buffers are live from the fork to the join; the footprint is the live set, not the
+    layer count -- 720x1280 4 x 16 frames (BASELINE configs[4]) fits 16 GB where one allocation per activation took 42.6."""
+    from iip_uavsal_saliency_amd import UAVSal
+    from iip_uavsal_saliency_amd.engine import Engine, ARENA_ALIGN
+    m = UAVSal(time_dims=8).eval()
+    rnd = lambda n: (n + ARENA_ALIGN - 1) // ARENA_ALIGN * ARENA_ALIGN
+    for (C, T, H, W, cap_mb) in ((1, 8, 360, 640, 600), (8, 8, 360, 640, 4500), (4, 16, 720, 1280, 15500)):
+        e = Engine(m, "cpu", n_seq=C, seq_len=T, H=H, W=W, ctx_T=T, ctx_mode="clip", plan_only=True)
+        lay = e.arena_layout()
+        assert len(lay) == e.arena_stats["buffers"] > 80
+        for i, (a, oa, na, fa, la) in enumerate(lay):
+            assert fa <= la
+            for (b, ob, nb, fb, lb) in lay[:i]:
+                if not (la < fb or lb < fa):
+                    assert oa + rnd(na) <= ob or ob + rnd(nb) <= oa, (a, b)
+        st = e.arena_stats
+        assert st["live_bound_mb"] <= st["arena_mb"] <= cap_mb and st["arena_mb"] < 0.3 * st["unshared_mb"], st
+        # lanes: what the temporal branch of STBlock 0 touches on lane 6 is live from its fork to its join
+        names = [o["name"] for o in e.ops_meta]
+        fork = max(i for i, nm in enumerate(names) if nm == "fork6" and i < names.index("st0.sub.pw"))
+        join = min(i for i, nm in enumerate(names) if nm == "join6" and i > names.index("st0.sub.pw"))
+        te1 = [t for t in lay if t[0] == "st0_te1"][0]
+        assert te1[3] <= fork and te1[4] >= join
+    # taps keep their buffers to the end of the plan
+    e = Engine(m, "cpu", n_seq=1, seq_len=4, H=96, W=160, ctx_T=4, ctx_mode="tile", plan_only=True, taps=True)
+    last = len(e.ops_meta)
+    for nm in ("sfnet", "st0", "st1", "prefuse", "rnn", "fu320", "f6", "f13", "f17"):
+        assert [t for t in e.arena_layout() if t[0] == nm][0][4] == last, nm
+    # every bias_type plans (no prior at all: no concat buffers)
+    e0 = Engine(UAVSal(time_dims=4, bias_type=[0, 0, 0]).eval(), "cpu", n_seq=1, seq_len=4, H=96, W=160, ctx_T=4, ctx_mode="tile",
+                plan_only=True)
+    assert not any(t[0] in ("fu320", "cb192") for t in e0.arena_layout())
+
+
+@pytest.mark.parametrize("bias", [(1, 1, 1), (0, 0, 0), (1, 0, 1), (0, 1, 0)])
+def test_recording_pass_addresses_every_activation_inside_its_live_range(bias):
+    """The engine's SECOND pass on the CPU (tests/mock_plan.py: real shape queries, stubbed plan recording): every activation
+    address comes from the arena, which refuses one outside the buffer's declared live range -- so a recorder that forgets to
+    declare a use fails here, at build time, on every plan variant (taps, persistent state, clips, split-fp16 shadows, frame-
+    invariant priors, every bias_type).  Debug mode: one NaN fill per released buffer, on the main lane, right range."""
+    import mock_plan
+    from iip_uavsal_saliency_amd import UAVSal
+    m = UAVSal(time_dims=4, bias_type=list(bias)).eval()
+    small = dict(H=96, W=160, ctx_T=4)
+    variants = [dict(n_seq=1, seq_len=4, ctx_mode="tile", **small), dict(n_seq=1, seq_len=8, ctx_mode="tile", taps=True, **small),
+                dict(n_seq=2, seq_len=4, ctx_mode="clip", persistent=True, **small),
+                dict(n_seq=4, seq_len=4, ctx_mode="clip", precision="f16x3", **small),
+                dict(n_seq=1, seq_len=3, H=72, W=104, ctx_T=3, ctx_mode="clip", use_lanes=False)]
+    if bias[0] or bias[1]:
+        variants.append(dict(n_seq=1, seq_len=4, ctx_mode="clip", static_priors=True, **small))
+    for kw in variants:
+        for debug in (False, True):
+            m.arena_debug = debug
+            eng, mock = mock_plan.record(m, **kw)
+            assert mock.n == len(eng.ops_meta) and eng._arena is not None
+            fills = [o for o in eng.ops_meta if o["kind"] == "poison"]
+            if not debug:
+                assert not fills and not mock.fills
+                continue
+            by_range = {(eng._arena.data_ptr() + 4 * off, n): aid for aid, off, n, _, _ in eng.arena_layout()}
+            logical = len(eng.ops_meta) - len(fills)
+            released = [t for t in eng.arena_layout() if t[4] < logical - 1]
+            assert len(mock.fills) == len(fills) == len(released), (kw, len(fills), len(released))
+            for _, ptr, n, lane in mock.fills:
+                assert lane == 0 and (ptr, n) in by_range, (kw, lane)
+            # a fill sits behind the last op that may touch its buffer: `last` counts logical ops, fills excluded
+            pos, k = {}, 0
+            for o in eng.ops_meta:
+                if o["kind"] == "poison":
+                    pos[o["name"][len("poison:"):]] = k
+                else:
+                    k += 1
+            for aid, _, _, first, last in released:
+                assert pos[str(aid)] == last + 1, (aid, first, last, pos[str(aid)])
+
+
 def test_reference_style_whole_model_pickle_loads_through_the_shim(tmp_path):
     """A whole pickled model whose classes live in `model`, `model_feature`, `model_convlstm` and
     `torchvision.models.mobilenet` (as the reference's checkpoints do, Demo_Train_Test.py:159-160)
@@ -521,6 +626,29 @@ def test_bench_self_launch_fails_loudly(tmp_path, monkeypatch, capfd):
         f.unlink()
     assert bench.self_launch(2, [], worker=[sys.executable, str(stub), str(tmp_path)]) == 2
     assert "only 1 GPU(s) visible" in capfd.readouterr().err and not list(tmp_path.glob("rank*.json"))
+    # (c) every rank hangs (a collective nobody leaves, a hung GPU): the wall-clock limit stops them by PID and says which
+    monkeypatch.setenv("UAVSAL_BENCH_VISIBLE_GPUS", "2")
+    monkeypatch.setenv("STUB_FAIL_RANK", "99")            # nobody fails, everybody sleeps 120 s
+    t0 = time.perf_counter()
+    rc = bench.self_launch(2, [], worker=[sys.executable, str(stub), str(tmp_path)], deadline_s=3.0)
+    assert rc == 124 and time.perf_counter() - t0 < 40
+    assert "still running and have been stopped" in capfd.readouterr().err
+
+
+def test_bench_counts_gpus_without_a_hip_call(monkeypatch):
+    """The launcher's GPU count comes from the visibility variables or the KFD topology, not from the HIP runtime."""
+    bench = _bench_module()
+    monkeypatch.delenv("UAVSAL_BENCH_VISIBLE_GPUS", raising=False)
+    monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: (_ for _ in ()).throw(AssertionError("HIP was asked")))
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1,2")
+    assert bench.visible_gpus() == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
+    assert bench.visible_gpus() == 0
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    for var in ("CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    if os.path.isdir("/sys/class/kfd/kfd/topology/nodes"):
+        assert bench.visible_gpus() >= 0                 # read from sysfs: still no HIP call
 
 
 def test_bench_gpus_2_on_a_box_without_two_gpus_exits_nonzero():

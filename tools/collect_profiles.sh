@@ -1,10 +1,10 @@
-# How the profiles/r4_* set is produced on the GPU box (run through gpurun from the repo root; afterwards copy
-# gpurun_out/r4final/* into profiles/).  Per workload: rocprofv3 --kernel-trace --stats, two PMC passes (FETCH_SIZE,
+# How the profiles/r5_* set is produced on the GPU box (run through gpurun from the repo root; afterwards copy
+# gpurun_out/r5final/* into profiles/).  Per workload: rocprofv3 --kernel-trace --stats, two PMC passes (FETCH_SIZE,
 # WRITE_SIZE: separate runs, no tracing), the summaries bench.py quotes (stamped with the kernel-source hash), and the
 # bench line itself.  The program goes directly after `--`.
 set -e
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r4final
+O=$R/gpurun_out/r5final
 if [ -z "$ONLY_BENCH" ]; then rm -rf $O; fi      # ONLY_BENCH=1: just the bench lines again (bench.py changed, kernels did not)
 mkdir -p $O
 run_set() {   # $1 = prec, $2 = clips, $3 = label, $4 = file tag (bench.py _wl_tag), $5... = extra bench arguments
@@ -14,11 +14,11 @@ run_set() {   # $1 = prec, $2 = clips, $3 = label, $4 = file tag (bench.py _wl_t
   rocprofv3 --pmc WRITE_SIZE -d $O/w_$T -o w --output-format csv -- python3 $R/bench.py --prec $P --clips $C "$@" --no-cpu-baseline --no-extra --no-roofline --steps 5 --windows 1 > /dev/null 2> $O/w_$T.err
   rocprofv3 --kernel-trace --stats -d $O/kt_$T -o kt --output-format csv -- python3 $R/bench.py --prec $P --clips $C "$@" --no-cpu-baseline --no-extra --no-roofline > $O/kt_bench_$T.json 2> $O/kt_$T.err
   cd $R
-  python3 tools/traffic_report.py $O/f_$T/f_counter_collection.csv $O/w_$T/w_counter_collection.csv $O/r4_hbm_traffic_$T.json "$L" > $O/r4_hbm_traffic_$T.txt
-  python3 tools/kernel_stats_report.py $O/kt_$T/kt_kernel_stats.csv $O/r4_kernel_stats_$T.json "$L" > $O/r4_kernel_stats_$T.txt
-  cp $O/kt_$T/kt_kernel_stats.csv $O/r4_bench_${T}_kernel_stats.csv
-  python3 tools/step_timeline.py $O/kt_$T/kt_kernel_trace.csv 3 --list > $O/r4_step_timeline_$T.txt 2>/dev/null || true
-  cp $O/r4_hbm_traffic_$T.json $O/r4_kernel_stats_$T.json profiles/     # so that the bench line below can quote them
+  python3 tools/traffic_report.py $O/f_$T/f_counter_collection.csv $O/w_$T/w_counter_collection.csv $O/r5_hbm_traffic_$T.json "$L" > $O/r5_hbm_traffic_$T.txt
+  python3 tools/kernel_stats_report.py $O/kt_$T/kt_kernel_stats.csv $O/r5_kernel_stats_$T.json "$L" > $O/r5_kernel_stats_$T.txt
+  cp $O/kt_$T/kt_kernel_stats.csv $O/r5_bench_${T}_kernel_stats.csv
+  python3 tools/step_timeline.py $O/kt_$T/kt_kernel_trace.csv 3 --list > $O/r5_step_timeline_$T.txt 2>/dev/null || true
+  cp $O/r5_hbm_traffic_$T.json $O/r5_kernel_stats_$T.json profiles/     # so that the bench line below can quote them
   rm -rf $O/f_$T $O/w_$T $O/kt_$T/kt_kernel_trace.csv
 }
 if [ -z "$ONLY_BENCH" ]; then
@@ -28,10 +28,10 @@ run_set f16x3 8 "bench.py --prec f16x3 --clips 8 (configs[2]: 360x640, 8 clips x
 run_set f32 4 "bench.py --height 720 --width 1280 --frames 16 --clips 4 --persistent-state 1 (configs[4])" f32_c4_720x1280_t16 --height 720 --width 1280 --frames 16 --persistent-state 1 --steps 5 --warmup 2
 fi
 cd $R
-python3 bench.py > $O/r4_bench_default.json 2> $O/r4_bench_default.err
-python3 bench.py --clips 8 --no-extra --no-cpu-baseline > $O/r4_bench_f32_c8.json 2> $O/r4_bench_f32_c8.err
-python3 bench.py --prec f16x3 --clips 8 --no-extra --no-cpu-baseline > $O/r4_bench_f16x3_c8.json 2> $O/r4_bench_f16x3_c8.err
-python3 bench.py --prec f16x3 --no-extra --no-cpu-baseline > $O/r4_bench_f16x3_c1.json 2> $O/r4_bench_f16x3_c1.err
-python3 bench.py --height 720 --width 1280 --frames 16 --clips 4 --persistent-state 1 --steps 5 --warmup 2 --no-extra --no-cpu-baseline > $O/r4_bench_720p_c4_t16.json 2> $O/r4_bench_720p_c4_t16.err
-python3 bench.py --height 720 --width 1280 --frames 16 --clips 4 --persistent-state 0 --steps 5 --warmup 2 --no-extra --no-cpu-baseline --no-roofline > $O/r4_bench_720p_c4_t16_state_refed.json 2> $O/r4_bench_720p_c4_t16_state_refed.err
+python3 bench.py > $O/r5_bench_default.json 2> $O/r5_bench_default.err
+python3 bench.py --clips 8 --no-extra --no-cpu-baseline > $O/r5_bench_f32_c8.json 2> $O/r5_bench_f32_c8.err
+python3 bench.py --prec f16x3 --clips 8 --no-extra --no-cpu-baseline > $O/r5_bench_f16x3_c8.json 2> $O/r5_bench_f16x3_c8.err
+python3 bench.py --prec f16x3 --no-extra --no-cpu-baseline > $O/r5_bench_f16x3_c1.json 2> $O/r5_bench_f16x3_c1.err
+python3 bench.py --height 720 --width 1280 --frames 16 --clips 4 --persistent-state 1 --steps 5 --warmup 2 --no-extra --no-cpu-baseline > $O/r5_bench_720p_c4_t16.json 2> $O/r5_bench_720p_c4_t16.err
+python3 bench.py --height 720 --width 1280 --frames 16 --clips 4 --persistent-state 0 --steps 5 --warmup 2 --no-extra --no-cpu-baseline --no-roofline > $O/r5_bench_720p_c4_t16_state_refed.json 2> $O/r5_bench_720p_c4_t16_state_refed.err
 ls $O
