@@ -23,7 +23,9 @@ _ERR = {-1: "UAVSAL_EINVAL (null pointer / non-positive size)",
         -5: "UAVSAL_EDEVICE (a kernel reported a device-side error; the run's outputs are invalid)"}
 ERR_STREAMK = 1
 DW_KERNEL = {1: "dw3x3_kernel<1, 4, 4>", 2: "dw3x3_kernel<1, 2, 2>", 3: "dw3x3_kernel<2, 2, 2>", 4: "dw3x3_dilated_kernel",
-             16: "dw3x3_map_lds_kernel<16>", 32: "dw3x3_map_lds_kernel<32>", 64: "dw3x3_map_lds_kernel<64>"}
+             16: "dw3x3_map_lds_kernel<16, 256>", 32: "dw3x3_map_lds_kernel<32, 256>", 64: "dw3x3_map_lds_kernel<64, 256>",
+             528: "dw3x3_map_lds_kernel<16, 512>", 544: "dw3x3_map_lds_kernel<32, 512>", 576: "dw3x3_map_lds_kernel<64, 512>",
+             1040: "dw3x3_map_lds_kernel<16, 1024>", 1056: "dw3x3_map_lds_kernel<32, 1024>", 1088: "dw3x3_map_lds_kernel<64, 1024>"}
 
 _f = C.c_void_p   # device pointers travel as integers
 
@@ -124,7 +126,9 @@ class WinoDesc(C.Structure):
                 ("scale", _f), ("bias", _f), ("act", C.c_int32), ("epi", C.c_int32),
                 ("res", _f), ("ldr", C.c_int32), ("res_img_stride", C.c_int64),
                 ("aux", _f), ("ldx", C.c_int32), ("aux_img_stride", C.c_int64),
-                ("hprev", _f), ("ldh", C.c_int32), ("h_img_stride", C.c_int64)]
+                ("hprev", _f), ("ldh", C.c_int32), ("h_img_stride", C.c_int64),
+                ("n_seg", C.c_int32), ("seg_in", _f * 3), ("seg_ld", C.c_int32 * 3), ("seg_c", C.c_int32 * 3),
+                ("seg_H", C.c_int32 * 3), ("seg_W", C.c_int32 * 3)]
 
 
 DESC_TYPES = [ConvDesc, DwDesc, StemDesc, BilinearDesc, TdiffDesc, TsumDesc, LayoutDesc, PostDesc, GuardDesc, CopyDesc,
@@ -204,7 +208,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.uavsal_abi_version() != 19:
+    if lib.uavsal_abi_version() != 20:
         raise RuntimeError("libuavsal_hip.so ABI version mismatch")
     for i, t in enumerate(DESC_TYPES):
         if lib.uavsal_sizeof_desc(i) != C.sizeof(t):

@@ -158,8 +158,8 @@ __global__ __launch_bounds__(256) void dw3x3_dilated_kernel(const DwK p) {
 // 5760 channels (aspp.dw of BASELINE configs[4]): 0.37 of 8 TB/s before (profiles/r4_bench_720p_c4_t16.json).
 __device__ __attribute__((aligned(16))) float g_dw_zero[4];
 
-template <int CB>
-__global__ __launch_bounds__(256) void dw3x3_map_lds_kernel(const DwK p) {
+template <int CB, int NT = 256>
+__global__ __launch_bounds__(NT) void dw3x3_map_lds_kernel(const DwK p) {
     extern __shared__ __attribute__((aligned(16))) float smap[];
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
@@ -167,6 +167,7 @@ __global__ __launch_bounds__(256) void dw3x3_map_lds_kernel(const DwK p) {
     const int slabs = (p.C4 * 4 + CB - 1) / CB;
     const int vb = xcd_virtual_block(blockIdx.x, gridDim.x);
     const int n = vb / slabs, c0 = (vb - n * slabs) * CB;
+    static_assert(NT % Q == 0, "a thread keeps one channel quad");
     const int q = threadIdx.x % Q;
     const int c = c0 + q * 4;
     const bool cok = c < p.C4 * 4;                 // last slab may be narrower
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(256) void dw3x3_map_lds_kernel(const DwK p) {
     const float* inb = p.in + (size_t)n * HW * p.ldi + c;
     f32x4* sm = reinterpret_cast<f32x4*>(smap);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    for (int i0 = 0; i0 < HW * Q; i0 += 256) {     // (the LDS image is padded to whole 256-item rounds: launch_map_lds)
+    for (int i0 = 0; i0 < HW * Q; i0 += NT) {      // (the LDS image is padded to whole NT-item rounds: launch_map_lds)
         const int i = i0 + threadIdx.x;
         const int pix = i / Q;
         const float* src = (cok && pix < HW) ? inb + (size_t)pix * p.ldi : g_dw_zero;
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(256) void dw3x3_map_lds_kernel(const DwK p) {
     if (!cok) return;
     const int dil = p.dgc ? p.dils[c0 / p.dgc] : p.dil;          // (a slab never straddles two groups: dgc % CB == 0)
     float* outb = p.out + (size_t)n * HW * p.ldo + c;
-    for (int i = threadIdx.x; i < HW * Q; i += 256) {
+    for (int i = threadIdx.x; i < HW * Q; i += NT) {
         const int pix = i / Q;
         const int oy = pix / p.W, ox = pix - oy * p.W;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -215,13 +216,26 @@ __global__ __launch_bounds__(256) void dw3x3_map_lds_kernel(const DwK p) {
 }
 
 // LDS image of a slab: [pixel][CB / 4] float4 items, padded to whole rounds of 256 items (one LDS-DMA request per wave and round)
-static inline size_t map_lds_bytes(long long px, int cb) { return (size_t)((px * (cb / 4) + 255) / 256 * 256) * 16; }
+static inline size_t map_lds_bytes(long long px, int cb) { return (size_t)((px * (cb / 4) + 1023) / 1024 * 1024) * 16; }
+
+// threads per workgroup: 512 where a slab is many rounds of 256 items (the 23x40 map of 720x1280 inputs: 14.4 rounds; two
+// workgroups per CU by LDS either way, twice the waves to cover the store phase: 0.47 -> 0.52 of 8 TB/s at 64 frames)
+static inline int map_lds_threads(const DwK& k, int cb) {
+    static const int nt_forced = [] { const char* e = getenv("UAVSAL_DW_MAP_NT"); return e ? atoi(e) : 0; }();
+    if (nt_forced == 256 || nt_forced == 512 || nt_forced == 1024) return nt_forced;
+    return (long long)k.H * k.W * (cb / 4) >= 2048 ? 512 : 256;
+}
 
 template <int CB>
 int launch_map_lds(DwK k, hipStream_t s) {
     const int slabs = (k.C4 * 4 + CB - 1) / CB;
     const size_t smem = map_lds_bytes((long long)k.H * k.W, CB);
-    hipLaunchKernelGGL((dw3x3_map_lds_kernel<CB>), dim3((unsigned)(k.n_img * slabs)), dim3(256), smem, s, k);
+    // 512-thread workgroups where a slab is many rounds of 256 items (the 23x40 map of 720x1280 inputs: 14.4): two workgroups per
+    // CU by LDS either way, twice the waves to cover the store phase
+    const int nt = map_lds_threads(k, CB);
+    if (nt == 1024) hipLaunchKernelGGL((dw3x3_map_lds_kernel<CB, 1024>), dim3((unsigned)(k.n_img * slabs)), dim3(1024), smem, s, k);
+    else if (nt == 512) hipLaunchKernelGGL((dw3x3_map_lds_kernel<CB, 512>), dim3((unsigned)(k.n_img * slabs)), dim3(512), smem, s, k);
+    else hipLaunchKernelGGL((dw3x3_map_lds_kernel<CB, 256>), dim3((unsigned)(k.n_img * slabs)), dim3(256), smem, s, k);
     return uavsal_launch_status();
 }
 
@@ -243,7 +257,7 @@ static inline int map_lds_slab(const DwK& k) {
 }
 
 // which kernel a descriptor gets: 1 = dw3x3_kernel<1,4,4>, 2 = <1,2,2>, 3 = <2,2,2>, 4 = dw3x3_dilated_kernel,
-// 16 / 32 / 64 = dw3x3_map_lds_kernel<CB>
+// 16 / 32 / 64 = dw3x3_map_lds_kernel<CB> (uavsal_dw_variant adds 512 / 1024 for the instances with that many threads)
 static int dw_variant(const DwK& k, int stride, int dilation) {
     if (k.dgc) {              // several dilated branches in one launch: the whole-map kernel (each byte fetched once whatever the dilation)
         const int cb = map_lds_slab(k);
@@ -428,7 +442,9 @@ extern "C" int uavsal_dw_variant(const uavsal_dw_desc* d) {
     DwK k;
     k.H = d->H; k.W = d->W; k.Ho = (d->H - 1) / d->stride + 1; k.Wo = (d->W - 1) / d->stride + 1;
     k.C4 = d->C / 4; k.n_img = d->n_img; k.dgc = d->dil_group_c > 0 ? d->dil_group_c : 0;
-    return dw_variant(k, d->stride, d->dilation);
+    const int v = dw_variant(k, d->stride, d->dilation);
+    const int nt = v >= 16 ? map_lds_threads(k, v) : 256;
+    return nt == 256 ? v : v + nt;
 }
 
 extern "C" int uavsal_dw3x3_dot(const uavsal_dw_dot_desc* d, uavsal_stream_t stream) {

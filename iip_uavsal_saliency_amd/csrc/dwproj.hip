@@ -522,7 +522,8 @@ int launch_dwproj_variant(const ConvK& k0, hipStream_t stream) {
 template <int PREC>
 int launch_dwproj(const ConvK& k, hipStream_t stream) {
     static const int pw_mode = [] { const char* e = getenv("UAVSAL_DWPROJ_PW"); return e ? atoi(e) : 0; }();
-    if (k.Cout > 128 && pw_mode && PREC == UAVSAL_PREC_F32) return launch_dwproj_variant<PREC, 2, 4, 2, 2, 4>(k, stream);   // + 4 producer waves
+    if (k.Cout > 128 && ((pw_mode & 1) && PREC == UAVSAL_PREC_F32 || (pw_mode & 2) && PREC == UAVSAL_PREC_F16X3))
+        return launch_dwproj_variant<PREC, 2, 4, 2, 2, 4>(k, stream);   // + 4 producer waves (1: fp32, 2: split-fp16, 3: both)
     if (k.Cout > 128) return launch_dwproj_variant<PREC, 2, 4, 2, 2>(k, stream);   // 128 x 256, 8 waves
     if (k.Cout > 64) return launch_dwproj_variant<PREC, 2, 4, 2, 1>(k, stream);    // 128 x 128, 8 waves
     if (k.Cout > 32) return launch_dwproj_variant<PREC, 4, 2, 1, 1>(k, stream);    // 128 x 64,  8 waves

@@ -32,6 +32,11 @@ struct WinoK {
     int ldi, ldo, ldr, ldx, ldh;
     int n_img, H, W, C4, ty, tx, act, epi;
     long long total;
+    // input transform only: the input as channel segments of other tensors (uavsal_wino_desc.n_seg)
+    int nseg;
+    const float* sin[3];
+    int sld[3], sq1[3], sH[3], sW[3];          // sq1: one past the segment's last channel quad
+    float ssy[3], ssx[3];                       // align_corners scales (source - 1) / (H - 1), as uavsal_bilinear_ac computes them
 };
 
 // one-dimensional transforms (applied to rows, then to columns)
@@ -66,7 +71,11 @@ template <> struct WinoT<4> {
     }
 };
 
-template <int R>
+// SEG: the transform's input is a VIRTUAL concat of up to three tensors along the channels, each either at the map's size (read as
+// is) or on a smaller map and then resized on the fly exactly as uavsal_bilinear_ac does (ATen upsample_bilinear2d, align_corners) --
+// conv_last of the SRF-Net reads cat[up(x5), up(x4), lv3] (reference model.py:151-156) without the two resize launches and without
+// the 448-channel concat buffer ever existing (51.6 MB written and read back per 8 frames at 360x640).
+template <int R, bool SEG>
 __global__ __launch_bounds__(256) void wino_input_kernel(const WinoK p) {
     constexpr int P = WinoT<R>::P;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -79,17 +88,61 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const WinoK p) {
     const int tyi = r / p.tx, txi = r - tyi * p.tx;
     const int y0 = R * tyi - 1, x0 = R * txi - 1;
     const float* base = p.in + (size_t)n * p.in_is * p.ldi + c4 * 4;
+    int ldi = p.ldi, sW = p.W, sH = p.H;
+    bool resize = false;
+    float sy = 0.f, sx = 0.f;
+    if (SEG) {
+        const int s = c4 < p.sq1[0] ? 0 : (c4 < p.sq1[1] ? 1 : 2);
+        const int q0 = s == 0 ? 0 : (s == 1 ? p.sq1[0] : p.sq1[1]);
+        ldi = s == 0 ? p.sld[0] : (s == 1 ? p.sld[1] : p.sld[2]);
+        sH = s == 0 ? p.sH[0] : (s == 1 ? p.sH[1] : p.sH[2]);
+        sW = s == 0 ? p.sW[0] : (s == 1 ? p.sW[1] : p.sW[2]);
+        sy = s == 0 ? p.ssy[0] : (s == 1 ? p.ssy[1] : p.ssy[2]);
+        sx = s == 0 ? p.ssx[0] : (s == 1 ? p.ssx[1] : p.ssx[2]);
+        const float* b0 = s == 0 ? p.sin[0] : (s == 1 ? p.sin[1] : p.sin[2]);
+        base = b0 + (size_t)n * sH * sW * ldi + (c4 - q0) * 4;
+        resize = sH != p.H || sW != p.W;
+    }
+    // rows of the patch on the source map (resized segments): y0 / y1 / weight, as bilinear_kernel computes them
+    int ry0[P], ry1[P];
+    float rly[P];
+    if (SEG && resize) {
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            const int y = y0 + i;
+            const float fy = sy * (float)y;
+            const int a = (int)fy;
+            ry0[i] = a; ry1[i] = a + (a < sH - 1 ? 1 : 0); rly[i] = fy - (float)a;
+        }
+    }
     f32x4 t[P][P];                                       // t[i][j] = (B^T d)[i][j], built column by column
 #pragma unroll
     for (int j = 0; j < P; ++j) {
         const int x = x0 + j;
         f32x4 col[P], tc[P];
+        int cx0 = 0, cx1 = 0;
+        float lx = 0.f;
+        if (SEG && resize) {
+            const float fx = sx * (float)x;
+            cx0 = (int)fx; cx1 = cx0 + (cx0 < sW - 1 ? 1 : 0); lx = fx - (float)cx0;
+        }
 #pragma unroll
         for (int i = 0; i < P; ++i) {
             const int y = y0 + i;
-            col[i] = (y >= 0 && y < p.H && x >= 0 && x < p.W)
-                         ? *reinterpret_cast<const f32x4*>(base + ((size_t)y * p.W + x) * p.ldi)
-                         : (f32x4){0.f, 0.f, 0.f, 0.f};
+            const bool ok = y >= 0 && y < p.H && x >= 0 && x < p.W;
+            if (SEG && resize) {
+                col[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (ok) {
+                    const float ly = rly[i], hy = 1.f - ly, hx = 1.f - lx;
+                    const f32x4 v00 = *reinterpret_cast<const f32x4*>(base + ((size_t)ry0[i] * sW + cx0) * ldi);
+                    const f32x4 v01 = *reinterpret_cast<const f32x4*>(base + ((size_t)ry0[i] * sW + cx1) * ldi);
+                    const f32x4 v10 = *reinterpret_cast<const f32x4*>(base + ((size_t)ry1[i] * sW + cx0) * ldi);
+                    const f32x4 v11 = *reinterpret_cast<const f32x4*>(base + ((size_t)ry1[i] * sW + cx1) * ldi);
+                    col[i] = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+                }
+            } else {
+                col[i] = ok ? *reinterpret_cast<const f32x4*>(base + ((size_t)y * p.W + x) * ldi) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
         }
         WinoT<R>::bt(col, tc);
 #pragma unroll
@@ -169,10 +222,30 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const WinoK p) {
 }
 
 int fill(const uavsal_wino_desc* d, WinoK& k, bool input) {
-    if (!d || !d->in || !d->out) return UAVSAL_EINVAL;
+    if (!d || !d->out) return UAVSAL_EINVAL;
+    const bool seg = input && d->n_seg > 0;
+    if (!seg && !d->in) return UAVSAL_EINVAL;
+    if (d->n_seg < 0 || d->n_seg > 3 || (!input && d->n_seg)) return UAVSAL_EINVAL;
     if (d->n_img <= 0 || d->H <= 0 || d->W <= 0 || d->C <= 0) return UAVSAL_EINVAL;
-    if ((d->C & 3) || (d->ldi & 3) || (d->ldo & 3) || d->ldi < d->C || d->ldo < d->C) return UAVSAL_EALIGN;
-    if (!uavsal_aligned16(d->in) || !uavsal_aligned16(d->out)) return UAVSAL_EALIGN;
+    if ((d->C & 3) || (d->ldo & 3) || d->ldo < d->C) return UAVSAL_EALIGN;
+    if (!seg && ((d->ldi & 3) || d->ldi < d->C || !uavsal_aligned16(d->in))) return UAVSAL_EALIGN;
+    if (!uavsal_aligned16(d->out)) return UAVSAL_EALIGN;
+    k.nseg = 0;
+    for (int s = 0; s < 3; ++s) { k.sin[s] = nullptr; k.sld[s] = 0; k.sq1[s] = 0x7fffffff; k.sH[s] = d->H; k.sW[s] = d->W; k.ssy[s] = k.ssx[s] = 0.f; }
+    if (seg) {
+        int c = 0;
+        for (int s = 0; s < d->n_seg; ++s) {
+            if (!d->seg_in[s] || d->seg_c[s] <= 0 || d->seg_H[s] <= 0 || d->seg_W[s] <= 0) return UAVSAL_EINVAL;
+            if ((d->seg_c[s] & 3) || (d->seg_ld[s] & 3) || d->seg_ld[s] < d->seg_c[s] || !uavsal_aligned16(d->seg_in[s])) return UAVSAL_EALIGN;
+            c += d->seg_c[s];
+            k.sin[s] = d->seg_in[s]; k.sld[s] = d->seg_ld[s]; k.sq1[s] = c / 4; k.sH[s] = d->seg_H[s]; k.sW[s] = d->seg_W[s];
+            k.ssy[s] = d->H > 1 ? (float)(d->seg_H[s] - 1) / (float)(d->H - 1) : 0.f;
+            k.ssx[s] = d->W > 1 ? (float)(d->seg_W[s] - 1) / (float)(d->W - 1) : 0.f;
+        }
+        if (c != d->C) return UAVSAL_ESHAPE;
+        k.sq1[d->n_seg - 1] = 0x7fffffff;
+        k.nseg = d->n_seg;
+    }
     if (d->R != 2 && d->R != 4) return UAVSAL_ESHAPE;
     k.ty = (d->H + d->R - 1) / d->R; k.tx = (d->W + d->R - 1) / d->R;
     const long long tiles = (long long)d->n_img * k.ty * k.tx;
@@ -213,8 +286,12 @@ extern "C" int uavsal_wino_input(const uavsal_wino_desc* d, uavsal_stream_t stre
     WinoK k;
     const int e = fill(d, k, true);
     if (e) return e;
-    if (d->R == 4) hipLaunchKernelGGL(wino_input_kernel<4>, dim3((unsigned)((k.total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, k);
-    else hipLaunchKernelGGL(wino_input_kernel<2>, dim3((unsigned)((k.total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, k);
+    const dim3 grid((unsigned)((k.total + 255) / 256));
+    if (k.nseg) {
+        if (d->R == 4) hipLaunchKernelGGL((wino_input_kernel<4, true>), grid, dim3(256), 0, (hipStream_t)stream, k);
+        else hipLaunchKernelGGL((wino_input_kernel<2, true>), grid, dim3(256), 0, (hipStream_t)stream, k);
+    } else if (d->R == 4) hipLaunchKernelGGL((wino_input_kernel<4, false>), grid, dim3(256), 0, (hipStream_t)stream, k);
+    else hipLaunchKernelGGL((wino_input_kernel<2, false>), grid, dim3(256), 0, (hipStream_t)stream, k);
     return uavsal_launch_status();
 }
 

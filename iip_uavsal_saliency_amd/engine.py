@@ -77,6 +77,8 @@ MID_MAX_WGS = int(os.environ.get("UAVSAL_MID_MAX_WGS", "288"))
 
 
 # features[14..17] (12x20 maps at 360x640: 12 launches of 6-22 us, none of them a round of the chip) as two half-batch chains on two lanes
+WINO_TAIL_PLANES = int(os.environ.get("UAVSAL_WINO_TAIL_PLANES", "0"))
+WINO_SEG = int(os.environ.get("UAVSAL_WINO_SEG", "1"))         # see the SRF-Net head in Engine._build
 TAIL_SPLIT = os.environ.get("UAVSAL_TAIL_SPLIT", "0") == "1"
 TAIL_SPLIT_FROM = int(os.environ.get("UAVSAL_TAIL_SPLIT_FROM", "14"))
 TAIL_SPLIT_MAX_FRAMES = int(os.environ.get("UAVSAL_TAIL_SPLIT_MAX_FRAMES", "16"))
@@ -90,6 +92,7 @@ def _dwproj_patch_waste(h, w):
     return ((h + 7) // 8 * 8) * ((w + 15) // 16 * 16) / float(h * w)
 
 
+BLOCK_CHUNK_BYTES = int(float(os.environ.get("UAVSAL_BLOCK_CHUNK_GB", "3")) * (1 << 30))     # see Engine.ir_block
 ARENA = os.environ.get("UAVSAL_ARENA", "1") == "1"          # 0: one allocation per activation for the life of the plan (rounds 1-4)
 ARENA_ALIGN = 1024                                            # floats (4 KB): every arena buffer starts on a page
 
@@ -99,11 +102,14 @@ class _ArenaRef:
     (positions on the main lane's timeline; a use on a side lane counts from that lane's fork to its join).  Stands where a
     tensor stood in `V.t`, so every view of the buffer shares it; `data_ptr()` refuses to hand out an address outside the
     live range while a plan is being recorded -- a recorder that forgot to declare a use fails there, at build time."""
-    __slots__ = ("eng", "aid", "numel_", "off", "first", "last", "pinned")
+    __slots__ = ("eng", "aid", "numel_", "off", "first", "last", "pinned", "lkey", "lfirst", "llast")
 
     def __init__(self, eng, aid, numel):
         self.eng, self.aid, self.numel_ = eng, aid, int(numel)
         self.off, self.first, self.last, self.pinned = None, None, None, False
+        # lkey: (lane, index of its fork) while every use so far was recorded on that lane between that fork and its join
+        # (its launches are then ordered among themselves on one stream: [lfirst, llast] in recording order), else "mixed"
+        self.lkey, self.lfirst, self.llast = None, None, None
 
     def numel(self):
         return self.numel_
@@ -112,35 +118,59 @@ class _ArenaRef:
         e = self.eng
         if e._dry:
             return 0
-        if e._recording and not self.pinned and not (self.first <= e._lop <= self.last):
+        lo, hi = (self.lfirst, self.llast) if isinstance(self.lkey, tuple) else (self.first, self.last)
+        if e._recording and not self.pinned and not (lo <= e._lop <= hi):
             raise RuntimeError("arena: %r is addressed by op %d outside its live range [%d, %d] -- a recorder did not declare "
-                               "this use (Engine._touch)" % (self.aid, e._lop, self.first, self.last))
+                               "this use (Engine._touch)" % (self.aid, e._lop, lo, hi))
         return e._arena.data_ptr() + 4 * self.off
 
     def tensor(self):
         return self.eng._arena[self.off:self.off + self.numel_]
 
 
+def arena_conflict(a, b):
+    """Are two buffers `(numel, first, last[, lane key, lane first, lane last])` ever live together?  [first, last] are positions
+    on the main lane's timeline (a side-lane use counts from the fork to the join); two buffers used ONLY on the same side lane
+    between the same fork and join are ordered by that lane's stream, so for them the recording-order ranges decide."""
+    if a[2] < b[1] or b[2] < a[1]:
+        return False
+    if len(a) > 3 and len(b) > 3 and a[3] is not None and a[3] == b[3] and isinstance(a[3], tuple):
+        return not (a[5] < b[4] or b[5] < a[4])
+    return True
+
+
 def plan_arena(bufs, align=ARENA_ALIGN):
-    """Offsets for buffers `[(numel, first, last), ...]` such that two buffers whose live ranges intersect never overlap:
-    biggest first, each at the lowest aligned offset free of every already-placed buffer it is live together with.
-    Returns (offsets, total floats, lower bound = the largest sum of simultaneously live sizes)."""
+    """Offsets for buffers `[(numel, first, last[, lane key, lane first, lane last]), ...]` such that two buffers that are ever
+    live together (`arena_conflict`) never overlap: biggest first, each at the lowest aligned offset free of every already-placed
+    buffer it conflicts with.  Returns (offsets, total floats, lower bound = the largest sum of sizes live at one main-lane position)."""
     order = sorted(range(len(bufs)), key=lambda i: (-bufs[i][0], bufs[i][1]))
     placed, offs = [], [0] * len(bufs)
     rnd = lambda n: (n + align - 1) // align * align
     for i in order:
-        n, f, l = bufs[i]
-        busy = sorted((o, o + rnd(m)) for (o, m, f2, l2) in placed if not (l2 < f or l < f2))
+        n, f, l = bufs[i][:3]
+        busy = sorted((o, o + rnd(bufs[j][0])) for (o, j) in placed if arena_conflict(bufs[i], bufs[j]))
         at = 0
         for lo, hi in busy:
             if at + rnd(n) <= lo:
                 break
             at = max(at, hi)
         offs[i] = at
-        placed.append((at, n, f, l))
-    total = max([o + rnd(m) for (o, m, _, _) in placed], default=0)
-    events = sorted(set(f for _, f, _ in bufs))
-    bound = max([sum(rnd(n) for (n, f, l) in bufs if f <= t <= l) for t in events], default=0)
+        placed.append((at, i))
+    total = max([o + rnd(bufs[j][0]) for (o, j) in placed], default=0)
+    # lower bound: at a main-lane position, everything live there -- of the buffers that are private to one side lane only the
+    # largest set that is live together in that lane's own order
+    events = sorted(set(b[1] for b in bufs))
+    bound = 0
+    for t in events:
+        live = [b for b in bufs if b[1] <= t <= b[2]]
+        tot = sum(rnd(b[0]) for b in live if not (len(b) > 3 and isinstance(b[3], tuple)))
+        lanes = {}
+        for b in live:
+            if len(b) > 3 and isinstance(b[3], tuple):
+                lanes.setdefault(b[3], []).append(b)
+        for grp in lanes.values():
+            tot += max(sum(rnd(c[0]) for c in grp if c[4] <= u <= c[5]) for u in set(c[4] for c in grp))
+        bound = max(bound, tot)
     return offs, total, bound
 
 
@@ -348,11 +378,16 @@ class Engine:
             if not isinstance(r, _ArenaRef):
                 continue
             lo = hi = self._lop
+            key = "main"
             if self._lane != 0:
                 lo = self._lane_open.get(self._lane, lo)
                 self._lane_refs.setdefault(self._lane, set()).add(r)
+                key = (self._lane, self._lane_open.get(self._lane, -1))
             r.first = lo if r.first is None else min(r.first, lo)
             r.last = hi if r.last is None else max(r.last, hi)
+            r.lkey = key if r.lkey in (None, key) else "mixed"
+            r.lfirst = self._lop if r.lfirst is None else min(r.lfirst, self._lop)
+            r.llast = self._lop if r.llast is None else max(r.llast, self._lop)
 
     def _close_lanes(self):
         for lane in list(self._lane_refs):          # (a lane the plan never joined: live to the end)
@@ -367,13 +402,13 @@ class Engine:
         last_op = len(self.ops_meta)
         for r in refs:
             if r.first is None:                      # declared, never used by an op: keep it addressable for the whole plan
-                r.first, r.last = 0, last_op
+                r.first, r.last, r.lkey, r.lfirst, r.llast = 0, last_op, "mixed", 0, last_op
         if self.keep_taps:                           # read back after the run (Engine.tap)
             for k in self.TAP_NAMES:
                 v = self.named.get(k)
                 if v is not None and isinstance(v.t, _ArenaRef):
-                    v.t.last = last_op
-        offs, total, bound = plan_arena([(r.numel_, r.first, r.last) for r in refs])
+                    v.t.last, v.t.lkey = last_op, "mixed"
+        offs, total, bound = plan_arena([(r.numel_, r.first, r.last, r.lkey, r.lfirst, r.llast) for r in refs])
         for r, o in zip(refs, offs):
             r.off = o
         self.arena_stats = {"arena_mb": total * 4 / 1e6, "live_bound_mb": bound * 4 / 1e6,
@@ -385,30 +420,39 @@ class Engine:
             self._arena.fill_(float("nan"))
 
     def arena_layout(self):
-        """[(buffer id, offset, floats, first op, last op)] of the activation arena, by offset."""
-        return sorted(((r.aid, r.off, r.numel_, r.first, r.last) for r in self._refs.values()), key=lambda t: (t[1], t[3]))
+        """[(buffer id, offset, floats, first op, last op, lane key, first / last op in recording order)] of the arena, by offset
+        (engine.arena_conflict takes `t[2:]`)."""
+        return sorted(((r.aid, r.off, r.numel_, r.first, r.last, r.lkey, r.lfirst, r.llast) for r in self._refs.values()),
+                      key=lambda t: (t[1], t[3]))
 
     def _flush_poison(self, final=False):
         """Debug mode: once the op that ends a buffer's live range has been recorded -- and before anything of the next op,
         a fork included -- the range is filled with NaN on the main lane, so a use after release cannot go unnoticed."""
         if not (self.arena_debug and self.use_arena) or self._dry:
             return
+        def end_of(r):          # last logical op that may touch the buffer
+            return r.llast if isinstance(r.lkey, tuple) else r.last
         due = [r for r in self._refs.values() if r not in self._poison_done and not r.pinned
-               and (final or r.last < self._lop + 1)]
+               and (final or end_of(r) < self._lop + 1)]
         if not due:
             return
-        if self._lane != 0:
-            L.check(self.lib.uavsal_plan_set_lane(self.plan, 0), "plan_set_lane")
+        cur = self._lane
         for r in sorted(due, key=lambda r_: r_.off):
             self._poison_done.add(r)
-            if final and r.last >= self._lop:        # still live at the end of the plan (taps, the history the state is read from)
+            if final and end_of(r) >= self._lop:     # still live at the end of the plan (taps, the history the state is read from)
                 continue
+            # a buffer private to a side lane is released in that lane's own order: its fill goes on that lane (while the lane is
+            # open: behind its last launch there, in front of whatever the lane runs next), everything else on the main lane
+            lane = r.lkey[0] if isinstance(r.lkey, tuple) and self._lane_open.get(r.lkey[0]) == r.lkey[1] else 0
+            if lane != cur:
+                L.check(self.lib.uavsal_plan_set_lane(self.plan, lane), "plan_set_lane")
+                cur = lane
             self._op_idx["poison:%s" % (r.aid,)] = len(self.ops_meta)
-            self.ops_meta.append(dict(kind="poison", name="poison:%s" % (r.aid,), flops=0.0, bytes=4.0 * r.numel_))
+            self.ops_meta.append(dict(kind="poison", name="poison:%s" % (r.aid,), flops=0.0, bytes=4.0 * r.numel_, lane=lane))
             d = L.FillDesc()
             d.out, d.n, d.bits = self._arena.data_ptr() + 4 * r.off, r.numel_, 0x7FC00000
             self._add(self.lib.uavsal_plan_add_fill, d, "plan_add_fill")
-        if self._lane != 0:
+        if cur != self._lane:
             L.check(self.lib.uavsal_plan_set_lane(self.plan, self._lane), "plan_set_lane")
 
     def _scr_split(self, n, h, w, c) -> V:
@@ -654,10 +698,13 @@ class Engine:
         self.ops_meta[-1]["dwproj"] = dwproj
         self._add(self.lib.uavsal_plan_add_conv, d, "plan_add_conv(%s)" % name)
 
-    def conv3_wino(self, name, a: V, conv, bn, out: V, act, wslice=None, n_img=None, strides=None, twa=None, gemm_tile=0, r=2):
+    def conv3_wino(self, name, a: V, conv, bn, out: V, act, wslice=None, n_img=None, strides=None, twa=None, gemm_tile=0, r=2,
+                   segs=None):
         """Dense 3x3 conv (stride 1, padding 1) as Winograd F(r x r, 3x3), exact-fp32 mode only: input transform, ONE GEMM
         launch over the (r + 2)^2 transform planes (per-plane weights), output transform with the epilogue -- 2.25x (r = 2)
-        or 4x (r = 4) fewer MFMA FLOPs than the implicit GEMM (csrc/winograd.hip).  `twa=(x_t, pre_t)`: ConvTWA update in the output transform."""
+        or 4x (r = 4) fewer MFMA FLOPs than the implicit GEMM (csrc/winograd.hip).  `twa=(x_t, pre_t)`: ConvTWA update in the output transform.
+        `segs`: the input is the channel concatenation of these views, each resized to `a`'s map size inside the input transform
+        when it lives on a smaller map (uavsal_wino_desc.n_seg); `a` then only carries the shape (its `t` is None)."""
         cin, cout = a.c, out.c
         n = a.n if n_img is None else n_img
         hw = a.h * a.w
@@ -667,18 +714,25 @@ class Engine:
         st = strides or {}
         v = self._scr("WV", pp, mp, 1, cin)
         mm = self._scr("WM", pp, mp, 1, cout)
-        self._meta(kind="wino_in", name=name + ".xin", flops=0.0, bytes=4.0 * (n * hw * cin + float(pp) * tiles * cin))
-        self._touch(a, v)
+        in_bytes = 4.0 * (sum(sg.n * sg.h * sg.w * sg.c for sg in segs) if segs else n * hw * cin)
+        self._meta(kind="wino_in", name=name + ".xin", flops=0.0, bytes=in_bytes + 4.0 * float(pp) * tiles * cin)
+        self._touch(a, v, *(segs or ()))
         if not self._dry:
             wi = L.WinoDesc()
-            wi.inp, wi.ldi, wi.in_img_stride = a.ptr, a.ld, st.get("a", hw)
+            if segs:
+                assert sum(sg.c for sg in segs) == cin and len(segs) <= 3 and not strides
+                wi.n_seg = len(segs)
+                for i, sg in enumerate(segs):
+                    wi.seg_in[i], wi.seg_ld[i], wi.seg_c[i], wi.seg_H[i], wi.seg_W[i] = sg.ptr, sg.ld, sg.c, sg.h, sg.w
+            else:
+                wi.inp, wi.ldi, wi.in_img_stride = a.ptr, a.ld, st.get("a", hw)
             wi.out, wi.ldo = v.ptr, cin
             wi.n_img, wi.H, wi.W, wi.C, wi.Mp, wi.R = n, a.h, a.w, cin, mp, r
             self._add(self.lib.uavsal_plan_add_wino_input, wi, "plan_add_wino_input(%s)" % name)
-        self._meta(kind="conv1", name=name, flops=2.0 * pp * tiles * cin * cout,
-                   bytes=4.0 * pp * (tiles * (cin + cout) + cin * cout), M=pp * mp, K=cin, Nc=cout,
-                   direct_flops=2.0 * n * hw * cin * cout * 9)
-        self._touch(v, mm)
+        # WINO_TAIL_PLANES (experiment): the planes that only fill the GEMM's last, partial round of 128 x 128 tiles (36 planes x
+        # 15 x 2 tiles on 512 resident workgroups = 2.1 rounds) as a second launch on 64 x 64 tiles
+        tail = WINO_TAIL_PLANES if (gemm_tile in (0, 8) and twa is None and pp > WINO_TAIL_PLANES > 0) else 0
+        plane_parts = [(0, pp - tail, gemm_tile, name)] + ([(pp - tail, tail, 11, name + ".tail")] if tail else [])
         if not self._dry:
             key = ("wino", id(conv), wslice, r)
             if key not in self._wcache:
@@ -686,20 +740,26 @@ class Engine:
                 if wslice is not None:
                     w = w[:, wslice[0]:wslice[1]]
                 self._wcache[key] = self._dev(P.pack_wino_weight(w, r))
+        wgs = P.roundup(cout, 32) * P.roundup(cin, 32)
+        for (p0, pn, tile_, nm_) in plane_parts:
+            self._meta(kind="conv1", name=nm_, flops=2.0 * pn * tiles * cin * cout,
+                       bytes=4.0 * pn * (tiles * (cin + cout) + cin * cout), M=pn * mp, K=cin, Nc=cout,
+                       direct_flops=2.0 * n * hw * cin * cout * 9 * pn / pp)
+            self._touch(v, mm)
+            if self._dry:
+                continue
             d = L.ConvDesc()
-            d.a, d.lda, d.a_img_stride = v.ptr, cin, mp
-            d.w, d.w_group_stride = self._wcache[key].data_ptr(), P.roundup(cout, 32) * P.roundup(cin, 32)
-            d.out, d.ldc, d.o_img_stride = mm.ptr, cout, mp
-            d.n_img, d.H, d.W, d.Cin, d.Cout, d.taps = pp, mp, 1, cin, cout, 1
-            d.prec, d.act, d.epi, d.tile = L.PREC["f32"], L.ACT_NONE, L.EPI_AFFINE, gemm_tile      # Winograd plans are exact fp32
+            d.a, d.lda, d.a_img_stride = v.ptr + 4 * p0 * mp * cin, cin, mp
+            d.w, d.w_group_stride = self._wcache[key].data_ptr() + 4 * p0 * wgs, wgs
+            d.out, d.ldc, d.o_img_stride = mm.ptr + 4 * p0 * mp * cout, cout, mp
+            d.n_img, d.H, d.W, d.Cin, d.Cout, d.taps = pn, mp, 1, cin, cout, 1
+            d.prec, d.act, d.epi, d.tile = L.PREC["f32"], L.ACT_NONE, L.EPI_AFFINE, tile_      # Winograd plans are exact fp32
             d.err = self._err
-            self.ops_meta[-1]["split"] = False
-            self.ops_meta[-1]["tile"] = int(self.lib.uavsal_conv_tile(C.byref(d)))
-            self.ops_meta[-1]["streamk"] = 0
-            self.ops_meta[-1]["dwproj"] = 0
-            self._add(self.lib.uavsal_plan_add_conv, d, "plan_add_conv(%s)" % name)
+            m_ = self.ops_meta[-1]
+            m_["split"], m_["tile"], m_["streamk"], m_["dwproj"] = False, int(self.lib.uavsal_conv_tile(C.byref(d))), 0, 0
+            self._add(self.lib.uavsal_plan_add_conv, d, "plan_add_conv(%s)" % nm_)
         self._meta(kind="wino_out", name=name + ".xout", flops=0.0, bytes=4.0 * (float(pp) * tiles * cout + n * hw * cout))
-        self._touch(mm, out, a, *(twa or ()))
+        self._touch(mm, out, *(twa or ()), *((a,) if twa is not None else ()))
         if out.key is not None and self._dry:
             self._no_shadow.add(out.key)            # the output transform does not write split shadows
         if not self._dry:
@@ -879,6 +939,24 @@ class Engine:
             return
         seq = blk.conv
         stride, dil = blk.stride, getattr(blk, "dilation", 1)
+        # a block whose expanded tensor would be bigger than BLOCK_CHUNK_BYTES runs in chunks of whole frames (the block is
+        # per-frame arithmetic; the launches stay many rounds of the chip): the arena's peak is set by the biggest E, not by
+        # the layer count -- 720x1280 x 64 frames: fucbst's 7.1 GB E in two halves, peak 16.97 -> ~13 GB
+        if (expanded is None and blk.expand_ratio != 1 and x.n > 1 and self.use_arena and out.c > 1      # (the decoder's map is bound per call by op name)
+                and 4 * x.n * x.h * x.w * blk.hidden > BLOCK_CHUNK_BYTES):
+            per = 4 * x.h * x.w * blk.hidden
+            step = max(1, BLOCK_CHUNK_BYTES // per)
+            nchunk = (x.n + step - 1) // step
+            step = (x.n + nchunk - 1) // nchunk                     # equal chunks
+            for ci, f0 in enumerate(range(0, x.n, step)):
+                cnt = min(step, x.n - f0)
+                self._ir_block_one("%s#%d" % (name, ci) if nchunk > 1 else name, x.frames(f0, cnt), blk, out.frames(f0, cnt), final_act)
+            return
+        self._ir_block_one(name, x, blk, out, final_act, expanded)
+
+    def _ir_block_one(self, name, x: V, blk, out: V, final_act=L.ACT_NONE, expanded: Optional[V] = None):
+        seq = blk.conv
+        stride, dil = blk.stride, getattr(blk, "dilation", 1)
         if blk.expand_ratio != 1:
             if expanded is not None:
                 e = expanded
@@ -921,9 +999,17 @@ class Engine:
         dev = self.device
         if not self._dry:
             # boundary staging (NCHW, as the reference caller hands them over)
-            self.x_in = torch.empty((N, 3, self.H, self.W), dtype=self.in_dtype, device=dev)
-            self.cb0_in = torch.empty((1 if self.static_priors else N, 8, h, w), dtype=torch.float32, device=dev)
-            self.cb1_in = torch.empty((1 if self.static_priors else N, 20, h, w), dtype=torch.float32, device=dev)
+            # (launch-loop mode binds the caller's tensors into the plan before every run: the staging tensors of the frames and
+            # priors are then shapes only -- zero-stride views of one 4 KB block, not 0.8 GB at 64 frames of 720x1280 -- and
+            # `launch` refuses to run a plan that was never bound)
+            def _stage(shape, dtype):
+                if self.inplace:
+                    return torch.zeros(1024, dtype=dtype, device=dev)[:1].expand(shape)
+                return torch.empty(shape, dtype=dtype, device=dev)
+            self.x_in = _stage((N, 3, self.H, self.W), self.in_dtype)
+            self.cb0_in = _stage((1 if self.static_priors else N, 8, h, w), torch.float32)
+            self.cb1_in = _stage((1 if self.static_priors else N, 20, h, w), torch.float32)
+            self._bound = False
             self.state_in = torch.zeros((self.n_seq, 256, h, w), dtype=torch.float32, device=dev)
             self.zero_state = torch.zeros((self.n_seq, 256, h, w), dtype=torch.float32, device=dev)    # never written
             self.state_out = torch.empty((self.n_seq, 256, h, w), dtype=torch.float32, device=dev)
@@ -1060,7 +1146,13 @@ class Engine:
         # 1/32 and 1/16 scale maps: spread them over lanes so they fill the chip together
         x5 = self._buf("x5", N, c5.h, c5.w, 256)
         x4 = self._buf("x4", N, c4.h, c4.w, 128)
-        cat = self._buf("srf_cat", N, h, w, 448)
+        # conv_last reads cat[interpolate(x5), interpolate(x4), conv_lv3(c3)] (model.py:151-156).  Winograd plans: the input
+        # transform reads the three tensors itself and resizes the two small ones on the fly (uavsal_wino_desc.n_seg) -- no resize
+        # launches, no concat buffer (WINO_SEG = 0: the round-4 form; 1: conv_lv4 / conv_lv3 stay on their side lane)
+        wino_last = self.winograd and self._prec_for("conv_last") == "f32"
+        seg_mode = WINO_SEG if wino_last else 0
+        cat = self._buf("srf_cat", N, h, w, 448) if not seg_mode else None
+        lv3 = self._buf("lv3", N, h, w, 64) if seg_mode else cat.slice(384, 64)
         branches = (sf.lv5_aspp2, sf.lv5_aspp3, sf.lv5_aspp4)
         aspp_lanes = int(os.environ.get("UAVSAL_ASPP_LANES", "1"))
         fork = self.fork if aspp_lanes else (lambda lane: None)
@@ -1103,11 +1195,14 @@ class Engine:
                 fork(3 + bi)
                 self.ir_block("aspp%d" % (bi + 2), c5, b, aspp.slice(256 * (bi + 1), 256))
                 self.main()
-        fork(6)
+        if seg_mode != 2:
+            fork(6)
         self.conv("conv_lv4", c4, sf.conv_lv4[0], sf.conv_lv4[1], x4, R6)
-        self.bilinear("up_c4", x4, cat.slice(256, 128))
-        self.conv("conv_lv3", c3, sf.conv_lv3[0], sf.conv_lv3[1], cat.slice(384, 64), R6)
-        self.main()
+        if not seg_mode:
+            self.bilinear("up_c4", x4, cat.slice(256, 128))
+        self.conv("conv_lv3", c3, sf.conv_lv3[0], sf.conv_lv3[1], lv3, R6)
+        if seg_mode != 2:
+            self.main()
         self.conv("aspp1", c5, sf.lv5_aspp1[0], sf.lv5_aspp1[1], aspp.slice(0, 256), R6)
         if not aspp_dw_merged:
             join(3)
@@ -1118,10 +1213,15 @@ class Engine:
             self.conv("aspp.pl", aspp_grouped.slice(0, hid), [b.conv[2] for b in branches], [b.conv[3] for b in branches],
                       aspp.slice(256, 768), NONE, cout=768, n_group=256)
         self.conv("conv_lv5", aspp, sf.conv_lv5[0], sf.conv_lv5[1], x5, R6)
-        self.bilinear("up_c5", x5, cat.slice(0, 256))
-        join(6)
+        if not seg_mode:
+            self.bilinear("up_c5", x5, cat.slice(0, 256))
+        if seg_mode != 2:
+            join(6)
         x = self._buf("sfnet", N, h, w, 256)
-        if self.winograd and self._prec_for("conv_last") == "f32":
+        if seg_mode:
+            self.conv3_wino("conv_last", V(None, N, h, w, 448), sf.conv_last[0], sf.conv_last[1], x, R6, r=self.winograd_r,
+                            segs=[x5, x4, lv3])
+        elif wino_last:
             self.conv3_wino("conv_last", cat, sf.conv_last[0], sf.conv_last[1], x, R6, r=self.winograd_r)
         else:
             self.conv("conv_last", cat, sf.conv_last[0], sf.conv_last[1], x, R6, taps=9)
@@ -1314,6 +1414,8 @@ class Engine:
                     "plan_graph_launch")
             cur.wait_stream(self._gstream)
         else:
+            if self.inplace and not self._bound:
+                raise RuntimeError("launch-loop plan was never bound to the caller's tensors (Engine.run does that)")
             L.check(self.lib.uavsal_plan_run(self.plan, 0, -1, self._stream()), "plan_run")
 
     def _is_resident(self, t, view) -> bool:
@@ -1379,6 +1481,7 @@ class Engine:
                 outs.append(o)
             st = (outs[0], outs[1]) if lstm else outs[0]
         self._hold = hold
+        self._bound = True
         return out, st
 
     def stage_inputs(self, x, cb0, cb1, state, cstate=None):

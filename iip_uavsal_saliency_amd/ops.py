@@ -141,12 +141,21 @@ def conv_gemm(x, weight, scale=None, bias=None, act=L.ACT_NONE, res=None, out=No
     return (out, shadow) if split_out else out
 
 
-def conv3x3_winograd(x, weight, scale=None, bias=None, act=L.ACT_NONE, res=None, twa=None, r=2):
+def conv3x3_winograd(x, weight, scale=None, bias=None, act=L.ACT_NONE, res=None, twa=None, r=2, size=None):
     """Dense 3x3 conv (stride 1, padding 1) through Winograd F(r x r, 3x3), r = 2 or 4, fp32: input transform, ONE GEMM
     launch over the (r + 2)^2 transform planes (per-plane weights), output transform with the epilogue.  `twa=(x_t, pre_t)`: `x` is
-    h_{t-1} and the output transform applies the ConvTWA update (model_convlstm.py:276-292)."""
+    h_{t-1} and the output transform applies the ConvTWA update (model_convlstm.py:276-292).
+    `x` may be a list of up to three NHWC tensors: the conv's input is their channel concatenation, each first resized to
+    `size = (h, w)` (bilinear, align_corners=True) when its map has another size -- inside the input transform
+    (uavsal_wino_desc.n_seg)."""
     lib = L.load()
-    ip, ldi, n, h, w, cin = _nhwc_view(x)
+    segs = None
+    if isinstance(x, (list, tuple)):
+        segs = [_nhwc_view(t) for t in x]
+        n, (h, w), cin = segs[0][2], size, sum(sg[5] for sg in segs)
+        ip, ldi, x = None, 0, x[0]
+    else:
+        ip, ldi, n, h, w, cin = _nhwc_view(x)
     cout = weight.shape[0]
     tiles = n * ((h + r - 1) // r) * ((w + r - 1) // r)
     pp = (r + 2) * (r + 2)
@@ -160,6 +169,10 @@ def conv3x3_winograd(x, weight, scale=None, bias=None, act=L.ACT_NONE, res=None,
     wi = L.WinoDesc()
     wi.inp, wi.ldi, wi.out, wi.ldo = ip, ldi, v.data_ptr(), cin
     wi.n_img, wi.H, wi.W, wi.C, wi.Mp, wi.R = n, h, w, cin, mp, r
+    if segs is not None:
+        wi.n_seg = len(segs)
+        for i, (sp_, sld_, sn_, sh_, sw_, sc_) in enumerate(segs):
+            wi.seg_in[i], wi.seg_ld[i], wi.seg_c[i], wi.seg_H[i], wi.seg_W[i] = sp_, sld_, sc_, sh_, sw_
     L.check(lib.uavsal_wino_input(C.byref(wi), st), "uavsal_wino_input")
     d = L.ConvDesc()
     d.a, d.lda, d.a_img_stride = v.data_ptr(), cin, mp

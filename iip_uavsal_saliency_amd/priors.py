@@ -11,7 +11,9 @@ Resized priors: when the stored map size differs from the requested one the refe
 each map with `padding()` (utils_data.py:321-343) -- cv2.resize (INTER_LINEAR) to the largest size of the
 same aspect ratio that fits, pasted centred into a zero array of dtype **uint8** (utils_data.py:460-464,
 595-599) -- so the [0,1] floats are truncated to {0,1} (only exact 1.0 survives).  `quirk=True` (default)
-reproduces that bit for bit given cv2's documented half-pixel rule; `quirk=False` keeps the resized floats.
+reproduces that rule -- pinned to cv2's DOCUMENTED half-pixel INTER_LINEAR mapping, not to cv2 itself (absent here), and the
+maps are resized in float32 where cv2 would resize a float64 prior file in double: a value that lands within one float32 ulp
+of 1.0 can fall on the other side of the truncation; `quirk=False` keeps the resized floats.
 Host-side numpy; this is caller code, not part of the device path.
 """
 from __future__ import annotations

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define UAVSAL_ABI_VERSION 19
+#define UAVSAL_ABI_VERSION 20
 
 /* argument errors */
 #define UAVSAL_EINVAL   (-1)  /* null pointer / non-positive size */
@@ -226,7 +226,8 @@ typedef struct uavsal_dw_desc {
 int uavsal_dw3x3(const uavsal_dw_desc* d, uavsal_stream_t stream);
 /* kernel instance `uavsal_dw3x3` will use for this descriptor; no launch.  1: dw3x3_kernel<1,4,4> (4x4 output
  * patch per thread), 2: <1,2,2>, 3: <2,2,2> (stride 2), 4: dw3x3_dilated_kernel (one pixel per thread),
- * 16 / 32 / 64: dw3x3_map_lds_kernel<CB> (whole map of a CB-channel slab staged in LDS; small maps, any dilation) */
+ * 16 / 32 / 64: dw3x3_map_lds_kernel<CB, 256> (whole map of a CB-channel slab staged in LDS by LDS-DMA; small maps, any
+ * dilation), + 512 (528 / 544 / 576) for its 512-thread instance (slabs of >= 2048 float4 items) */
 int uavsal_dw_variant(const uavsal_dw_desc* d);
 
 /*
@@ -353,6 +354,13 @@ typedef struct uavsal_wino_desc {
     const float* res;   int32_t ldr;  int64_t res_img_stride;
     const float* aux;   int32_t ldx;  int64_t aux_img_stride;
     const float* hprev; int32_t ldh;  int64_t h_img_stride;
+    /* uavsal_wino_input only, n_seg = 1..3 (else 0 and `in` as above): the input is the channel concatenation of n_seg tensors,
+     * seg_in[s] = [n_img][seg_H[s]][seg_W[s]][seg_ld[s]] NHWC with seg_c[s] channels (sum = C).  A segment on a map of another
+     * size is resized to H x W on the fly, bilinear with align_corners=True, with uavsal_bilinear_ac's arithmetic -- the head of
+     * the SRF-Net feeds conv_last with cat[interpolate(x5), interpolate(x4), lv3] (reference model.py:151-156): neither the
+     * resized maps nor the concat buffer exist then.  `in`, `ldi`, `in_img_stride` are ignored. */
+    int32_t n_seg;
+    const float* seg_in[3];  int32_t seg_ld[3], seg_c[3], seg_H[3], seg_W[3];
 } uavsal_wino_desc;
 
 int uavsal_wino_input(const uavsal_wino_desc* d, uavsal_stream_t stream);

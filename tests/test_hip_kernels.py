@@ -235,6 +235,32 @@ def test_conv3x3_winograd(ops, case, r):
 
 
 @pytest.mark.parametrize("r", [2, 4])
+@pytest.mark.parametrize("case", [((45, 80), [(256, 12, 20), (128, 23, 40), (64, 45, 80)], 2), ((9, 13), [(8, 3, 4), (24, 5, 7)], 3),
+                                  ((12, 20), [(32, 12, 20)], 1), ((23, 40), [(16, 1, 1), (12, 23, 40), (4, 12, 20)], 2)])
+def test_conv3x3_winograd_virtual_concat_with_resize(ops, case, r):
+    """The Winograd input transform reading a VIRTUAL concat: up to three tensors side by side along the channels, the ones on a
+    smaller map resized on the fly (bilinear, align_corners=True) -- the SRF-Net head's `conv_last(cat[interpolate(x5),
+    interpolate(x4), lv3])` (reference model.py:151-156) without resize launches or a concat buffer.  Against F.interpolate +
+    torch.cat + F.conv2d on the CPU, and against the same conv on the materialised concat (the resize arithmetic is
+    uavsal_bilinear_ac's: equal up to FMA contraction)."""
+    from iip_uavsal_saliency_amd import _lib as L
+    (h, w), segs, n = case
+    xs = [rnd((n, c, sh, sw), 80 + i, 2.0) for i, (c, sh, sw) in enumerate(segs)]
+    cin, cout = sum(c for c, _, _ in segs), 32
+    wt = rnd((cout, cin, 3, 3), 90, 1.0 / np.sqrt(9 * cin))
+    scale = rnd((cout,), 91) * 0.5 + 1.0
+    bias = rnd((cout,), 92)
+    cat = torch.cat([t if tuple(t.shape[2:]) == (h, w) else F.interpolate(t, size=(h, w), mode="bilinear", align_corners=True)
+                     for t in xs], 1)
+    ref = act_ref(F.conv2d(cat, wt, padding=1) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1), L.ACT_RELU6)
+    got = ops.conv3x3_winograd([nhwc(t) for t in xs], wt, scale, bias, act=L.ACT_RELU6, r=r, size=(h, w))
+    err = (nchw(got) - ref).abs().max().item()
+    assert err <= (2e-4 if r == 2 else 6e-4), (case, r, err)
+    whole = ops.conv3x3_winograd(nhwc(cat), wt, scale, bias, act=L.ACT_RELU6, r=r)
+    assert (got - whole).abs().max().item() <= 5e-5, (case, r)
+
+
+@pytest.mark.parametrize("r", [2, 4])
 @pytest.mark.parametrize("shape", [(1, 45, 80), (2, 12, 20), (3, 9, 13)])
 def test_twa_step_winograd(ops, shape, r):
     """ConvTWA step with the gate convolution through Winograd: the output transform applies sigmoid / convex update."""
