@@ -77,8 +77,10 @@ def traffic_file(C, prec, T=8, H=360, W=640):
     return os.path.join("profiles", "%s_hbm_traffic_%s.json" % (PROFILE_ROUND, _wl_tag(C, T, H, W, prec)))
 
 
-def inloop_file(C, prec, T=8, H=360, W=640):
-    return os.path.join("profiles", "%s_kernel_stats_%s.json" % (PROFILE_ROUND, _wl_tag(C, T, H, W, prec)))
+def inloop_file(C, prec, T=8, H=360, W=640, lanes0=False):
+    """Committed rocprofv3 kernel-stats summary of this workload's bench command; `lanes0`: the same command with --lanes 0 (every
+    kernel alone on the chip, in plan order)."""
+    return os.path.join("profiles", "%s_kernel_stats_%s%s.json" % (PROFILE_ROUND, _wl_tag(C, T, H, W, prec), "_lanes0" if lanes0 else ""))
 
 
 def _stamped(path, T, H, W):
@@ -113,11 +115,11 @@ def measured_traffic(symbol, C, T, H, W, prec):
     return round(rec["hbm_mb_per_launch"] * 1e6), src
 
 
-def in_loop_timing(symbol, C, T, H, W, prec):
+def in_loop_timing(symbol, C, T, H, W, prec, lanes0=False):
     """Average duration of the kernel instance INSIDE the timed loop (rocprofv3 --kernel-trace --stats of this bench
     command, tools/kernel_stats_report.py): lanes overlap there and kernels queue behind each other, so it differs from
     the isolated per-op hipEvent timing the `roofline` objects are computed from."""
-    f = inloop_file(C, prec, T, H, W)
+    f = inloop_file(C, prec, T, H, W, lanes0)
     blob, why = _stamped(f, T, H, W)
     if blob is None or symbol not in blob:
         return {"status": why if blob is None else "kernel not in the summary", "file": f}
@@ -247,22 +249,22 @@ def depthwise_family(groups):
     return fam
 
 
-def family_in_loop(fam, C, T, H, W, prec):
+def family_in_loop(fam, C, T, H, W, prec, lanes0=False):
     """The same depthwise launches INSIDE the timed loop: per instance the rocprofv3 average duration (committed kernel-stats
     summary of this bench command, stamped with the kernel sources) x its launches per step; neither warmed by back-to-back
     repeats on the same buffers (the isolated figure is) -- but stretched wherever another lane's kernels share the chip."""
     us, miss = 0.0, []
     for inst, rec in fam["instances"].items():
-        il = in_loop_timing(inst, C, T, H, W, prec)
+        il = in_loop_timing(inst, C, T, H, W, prec, lanes0)
         if il.get("status") != "ok":
             miss.append(inst)
             status = il.get("status")
             continue
         us += il["avg_launch_us"] * rec["launches"]
     if miss:
-        return {"status": status, "missing": miss, "file": inloop_file(C, prec, T, H, W)}
+        return {"status": status, "missing": miss, "file": inloop_file(C, prec, T, H, W, lanes0)}
     gbs = fam["alg_mb_per_step"] * 1e6 / (us * 1e-6) / 1e9
-    return {"status": "ok", "file": inloop_file(C, prec, T, H, W), "kernel_ms_per_step": round(us * 1e-3, 4),
+    return {"status": "ok", "file": inloop_file(C, prec, T, H, W, lanes0), "kernel_ms_per_step": round(us * 1e-3, 4),
             "achieved": round(gbs, 1), "frac": round(gbs / PEAK_HBM_GBS, 4)}
 
 
@@ -638,6 +640,7 @@ def main():
                 if big in fam["instances"]:
                     fam["instances"][big]["traffic"], _ = measured_traffic(big, C, T, H, W, args.prec)
                 fam["in_loop"] = family_in_loop(fam, C, T, H, W, args.prec)
+                fam["in_loop_lanes_off"] = family_in_loop(fam, C, T, H, W, args.prec, lanes0=True)
                 fam["timing"] = PER_OP_TIMING
                 result["roofline_dw"] = fam
             dots = {k: g for k, g in groups.items() if g["kind"] == "dw_dot"}
@@ -731,6 +734,7 @@ def main():
                     fam8["workload"] = result["scaling_reference"]["workload"]
                     fam8["share_of_kernel_time"] = round(fam8["kernel_ms_per_step"] / sum(g["ms"] for g in g8.values()), 3)
                     fam8["in_loop"] = family_in_loop(fam8, 8, T, H, W, args.prec)
+                    fam8["in_loop_lanes_off"] = family_in_loop(fam8, 8, T, H, W, args.prec, lanes0=True)
                     fam8["timing"] = PER_OP_TIMING
                     result["scaling_reference"]["roofline_dw"] = fam8
                 fus8 = fused_family(g8)

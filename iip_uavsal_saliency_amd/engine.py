@@ -78,7 +78,7 @@ MID_MAX_WGS = int(os.environ.get("UAVSAL_MID_MAX_WGS", "288"))
 
 # features[14..17] (12x20 maps at 360x640: 12 launches of 6-22 us, none of them a round of the chip) as two half-batch chains on two lanes
 WINO_TAIL_PLANES = int(os.environ.get("UAVSAL_WINO_TAIL_PLANES", "0"))
-WINO_SEG = int(os.environ.get("UAVSAL_WINO_SEG", "1"))         # see the SRF-Net head in Engine._build
+WINO_SEG = int(os.environ.get("UAVSAL_WINO_SEG", "0"))         # see the SRF-Net head in Engine._build (measured: not faster, off)
 TAIL_SPLIT = os.environ.get("UAVSAL_TAIL_SPLIT", "0") == "1"
 TAIL_SPLIT_FROM = int(os.environ.get("UAVSAL_TAIL_SPLIT_FROM", "14"))
 TAIL_SPLIT_MAX_FRAMES = int(os.environ.get("UAVSAL_TAIL_SPLIT_MAX_FRAMES", "16"))
@@ -92,7 +92,7 @@ def _dwproj_patch_waste(h, w):
     return ((h + 7) // 8 * 8) * ((w + 15) // 16 * 16) / float(h * w)
 
 
-BLOCK_CHUNK_BYTES = int(float(os.environ.get("UAVSAL_BLOCK_CHUNK_GB", "3")) * (1 << 30))     # see Engine.ir_block
+BLOCK_CHUNK_BYTES = int(float(os.environ.get("UAVSAL_BLOCK_CHUNK_GB", "6")) * (1 << 30))     # see Engine.ir_block
 ARENA = os.environ.get("UAVSAL_ARENA", "1") == "1"          # 0: one allocation per activation for the life of the plan (rounds 1-4)
 ARENA_ALIGN = 1024                                            # floats (4 KB): every arena buffer starts on a page
 
@@ -1238,7 +1238,10 @@ class Engine:
             # temporal branch (small launches): st_lanes 1 = all of it on lane 6, next to the spatial branch's big GEMMs;
             # 2 = its first two launches on the main lane (they would otherwise queue behind a grid-filling GEMM for
             # the whole of it), the rest on lane 6; 0 = no side lane
-            st_lanes = int(os.environ.get("UAVSAL_ST_LANES", "2"))     # (same box, two runs each: 5.26 / 5.25 / 5.22 ms for 1 / 0 / 2)
+            # (round 2, same box, two runs each: 5.26 / 5.25 / 5.22 ms for 1 / 0 / 2.  Round 5, one clip: 4.234 / 4.221 for 2 / 0 --
+            # the fork / join pair costs more than the overlap buys while the spatial branch's GEMMs fill the chip anyway; eight
+            # clips: 27.97-28.10 / 28.31 for 2 / 0.  A function of the frame count only)
+            st_lanes = int(os.environ.get("UAVSAL_ST_LANES", "0" if N <= 8 else "2"))
             if st_lanes == 1:
                 self.fork(6)
             self.conv("st%d.reduce" % i, x, te.reduce_conv[0], te.reduce_conv[1], r, R6)
