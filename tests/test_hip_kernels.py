@@ -600,6 +600,8 @@ DW_CASES = [
     # whole-map LDS kernel: last channel slab narrower than the slab, 8 images (slab 32), odd map, and a map
     # too large for LDS (generic dilated kernel)
     (1, 12, 20, 120, 1, 2), (8, 12, 20, 960, 1, 6), (3, 23, 40, 96, 1, 3), (1, 45, 80, 64, 1, 2), (2, 7, 5, 20, 1, 4),
+    # thousands of (image, slab) workgroups of the whole-map kernel (XCD-renumbered blocks), last slab narrower than 32 channels
+    (40, 12, 20, 3824, 1, 6), (36, 23, 40, 1840, 1, 6),
 ]
 
 
@@ -618,7 +620,8 @@ def test_depthwise(ops, case):
     assert err <= 1e-5, (case, err)       # 9 fp32 fmas per output, order may differ
 
 
-@pytest.mark.parametrize("case", [(8, 12, 20, 3 * 1920, (6, 12, 18)), (2, 9, 13, 192, (2, 3, 5)), (1, 45, 80, 128, (1, 4)), (2, 130, 140, 96, (3, 7, 1))])
+@pytest.mark.parametrize("case", [(8, 12, 20, 3 * 1920, (6, 12, 18)), (2, 9, 13, 192, (2, 3, 5)), (1, 45, 80, 128, (1, 4)), (2, 130, 140, 96, (3, 7, 1)),
+                                  (48, 9, 13, 3 * 960, (6, 2, 3))])        # (the last one: 4320 workgroups of the whole-map kernel)
 def test_depthwise_channel_groups_with_their_own_dilation(ops, case):
     """uavsal_dw_desc.dil_group_c: the dilated branches of one map in one launch (the three ASPP depthwise convs on the slices of
     their merged expand, model.py:125-127, 142-147) == one torch depthwise conv per group.  Whole-map LDS kernel where the map
