@@ -38,11 +38,13 @@ for k, (calls, va) in a.items():
     rows.append((calls * wc, k, calls, waves, cyc, va["SQ_WAIT_ANY"] / wc, va["SQ_WAIT_INST_ANY"] / wc, va["SQ_ACTIVE_INST_ANY"] / wc,
                  va["SQ_WAIT_INST_LDS"] / wc, va["SQ_INSTS_VALU"] / vb["SQ_INSTS_MFMA"] if vb["SQ_INSTS_MFMA"] else float("nan"),
                  vb["SQ_LDS_BANK_CONFLICT"] / vb["SQ_LDS_IDX_ACTIVE"] if vb["SQ_LDS_IDX_ACTIVE"] else 0.0,
-                 va["SQ_VALU_MFMA_BUSY_CYCLES"], va["SQ_VALU_MFMA_BUSY_CYCLES"] / (4 * cus) / cyc, vb["SQ_INSTS_VMEM"] / waves))
+                 va["SQ_VALU_MFMA_BUSY_CYCLES"], va["SQ_VALU_MFMA_BUSY_CYCLES"] / (4 * cus) / cyc if wgs <= 512 else float("nan"),
+                 vb["SQ_INSTS_VMEM"] / waves))
 print("| kernel | launches | waves per launch | cycles per wave | in s_waitcnt / barrier | in issue stalls | issuing | LDS issue stall | "
       "VALU per MFMA | LDS conflict / active | MFMA-busy cycles per launch | pipe busy | VMEM instr per wave |")
 print("|---|---|---|---|---|---|---|---|---|---|---|---|---|")
 for r in sorted(rows, reverse=True):
     _, k, calls, waves, cyc, w, st, act, lds, vpm, conf, busy, pb, vm = r
-    print("| `%s` | %d | %.0f | %.0f | %.0f %% | %.0f %% | %.0f %% | %.1f %% | %.1f | %.0f %% | %.3g | %.0f %% | %.0f |" % (
-        k, calls, waves, cyc, 100 * w, 100 * st, 100 * act, 100 * lds, vpm, 100 * conf, busy, 100 * pb, vm))
+    print("| `%s` | %d | %.0f | %.0f | %.0f %% | %.0f %% | %.0f %% | %.1f %% | %s | %.0f %% | %.3g | %s | %.0f |" % (
+        k, calls, waves, cyc, 100 * w, 100 * st, 100 * act, 100 * lds, "-" if vpm != vpm else "%.1f" % vpm, 100 * conf, busy,
+        "- (several rounds)" if pb != pb else "%.0f %%" % (100 * pb), vm))
