@@ -199,6 +199,33 @@ def test_winograd_and_direct_3x3_agree_end_to_end(hip_model, golden_dir):
     assert (outs[True] - outs[False]).abs().max().item() <= 2e-4
 
 
+def test_virtual_concat_winograd_input_end_to_end(hip_model, golden_dir):
+    """The opt-in form of the SRF-Net head (engine.WINO_SEG, measured not faster and therefore off): `conv_last`'s Winograd input
+    transform reads cat[interpolate(x5), interpolate(x4), lv3] itself (uavsal_wino_desc.n_seg, reference model.py:151-156) -- no
+    resize launches, no concat buffer.  Same maps as the default plan up to FMA contraction in the resize, inside the parity bound
+    of the reference's output; arena in NaN-poisoning debug mode, so the shorter live ranges are checked too."""
+    from iip_uavsal_saliency_amd import engine as E
+    g = np.load(os.path.join(golden_dir, "e2e_360x640_T8.npz"))
+    x, cb = make_inputs(8, 360, 640, int(g["seed"]))
+    outs, saved = {}, E.WINO_SEG
+    try:
+        for mode in (0, 1, 2):
+            E.WINO_SEG = mode
+            hip_model.invalidate_engines()
+            hip_model.arena_debug = mode != 0
+            outs[mode], _ = _run_hip(hip_model, 8, "f32", x, cb)
+            eng = list(hip_model._engines.values())[-1]
+            names = [o["name"] for o in eng.ops_meta]
+            assert ("up_c5" in names) == (mode == 0) and ("srf_cat" in eng.named) == (mode == 0)
+            err = np.abs(outs[mode].numpy() - g["out"]).max()
+            assert err <= MAP_TOL["f32"], (mode, err)
+    finally:
+        E.WINO_SEG = saved
+        hip_model.arena_debug = False
+        hip_model.invalidate_engines()
+    assert (outs[1] - outs[0]).abs().max().item() <= 5e-5 and torch.equal(outs[1], outs[2])
+
+
 def test_winograd_modes_agree_at_eight_clips(hip_model, golden_dir):
     """From four clips up the default exact-fp32 plan switches the recurrence steps to F(4x4): default,
     strict F(2x2) everywhere (`model.winograd_r = 2`) and direct 3x3 convs, on BASELINE configs[2]'s 8 clips x 8 frames --
