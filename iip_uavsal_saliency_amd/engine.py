@@ -77,6 +77,7 @@ MID_MAX_WGS = int(os.environ.get("UAVSAL_MID_MAX_WGS", "288"))
 
 
 # features[14..17] (12x20 maps at 360x640: 12 launches of 6-22 us, none of them a round of the chip) as two half-batch chains on two lanes
+F16X3_WINO_STEPS = int(os.environ.get("UAVSAL_F16X3_WINO_STEPS", "1"))
 WINO_TAIL_PLANES = int(os.environ.get("UAVSAL_WINO_TAIL_PLANES", "0"))
 WINO_SEG = int(os.environ.get("UAVSAL_WINO_SEG", "0"))         # see the SRF-Net head in Engine._build (measured: not faster, off)
 TAIL_SPLIT = os.environ.get("UAVSAL_TAIL_SPLIT", "0") == "1"
@@ -1336,7 +1337,12 @@ class Engine:
             a = h0 if t == 0 else ro.frames(t - 1, self.n_seq)
             a = V(a.t, self.n_seq, h, w, 256, 256, a.coff)
             strides = {"a": hw if t == 0 else Lq * hw, "o": Lq * hw, "r": Lq * hw, "x": Lq * hw}
-            if self.winograd and self.winograd_steps and self._prec_for("twa.step") == "f32":
+            # (split-fp16 plans from four clips up: the per-step gate convolution in exact fp32 through Winograd F(4x4) as well -- 1.78x
+            # fewer MFMA FLOPs than the direct 3x3 and it beats the split-fp16 implicit GEMM there: 136 vs 160 us per step at eight
+            # clips, 17.89 -> 17.67 ms per eight-clip step; more accurate, never less.  F16X3_WINO_STEPS = 0: the direct split-fp16 step)
+            f16_wino = (F16X3_WINO_STEPS and self.prec_name == "f16x3" and not self.prec_overrides and self.n_seq >= 4
+                        and bool(getattr(m, "winograd", True)))
+            if (self.winograd or f16_wino) and self.winograd_steps and (f16_wino or self._prec_for("twa.step") == "f32"):
                 # one clip: 920 tiles of 2x2 fill the chip with 128x128 GEMM tiles; four clips and more: F(4x4) (1.78x
                 # fewer FLOPs, smaller transforms) on 64x64 tiles (measured: 4.54 vs 4.61 ms at one clip, 29.47 vs 28.80 at eight)
                 many = self.n_seq >= 4
