@@ -375,6 +375,37 @@ def test_arena_is_bit_identical_and_never_reads_a_released_range(hip_model, prec
             hip_model.invalidate_engines()
 
 
+@pytest.mark.parametrize("prec", PARITY_PRECS)
+def test_arena_on_the_reference_surface_with_taps_and_lstm(hip_model, prec):
+    """`forward()` -- the reference's own surface: one sequence of B x time_dims frames, context prior tiled, taps read back after
+    the run -- and the ConvLSTM variant (cell-state history buffer), each as one allocation per activation vs the NaN-poisoned arena:
+    maps, states and every tap bit-identical."""
+    from iip_uavsal_saliency_amd import UAVSAL_LSTM
+    x, cb = make_inputs(20, 96, 160)
+    xd, cbd = x.cuda(), [cb[0].cuda(), cb[1].cuda()]
+    lstm = UAVSAL_LSTM(time_dims=5)
+    synth.load_synth_weights(lstm, 0)
+    lstm = lstm.cuda().eval()
+    for m in (hip_model, lstm):
+        m.time_dims, m.precision = 5, prec
+        got = {}
+        try:
+            for mode in ("unshared", "debug"):
+                m.arena, m.arena_debug = mode != "unshared", mode == "debug"
+                taps = {}
+                o1, s1 = m(xd, cbd, None, taps)
+                o2, s2 = m(xd, cbd, [tuple(s1)] if m.rnn_type == "lstm" else s1, None)           # second call, carried state, no taps
+                got[mode] = ([o1.clone(), o2.clone()] + [t.clone() for t in s1] + [t.clone() for t in s2], {k: v.clone() for k, v in taps.items()})
+                assert list(m._engines.values())[-1].use_arena == (mode != "unshared")
+        finally:
+            m.arena, m.arena_debug = True, False
+        for a, b in zip(got["unshared"][0], got["debug"][0]):
+            assert torch.equal(a, b) and bool(torch.isfinite(b).all().item())
+        assert sorted(got["unshared"][1]) == sorted(got["debug"][1]) and len(got["debug"][1]) >= 9
+        for k in got["unshared"][1]:
+            assert torch.equal(got["unshared"][1][k], got["debug"][1][k]), k
+
+
 def test_persistent_state_equals_refed_state(hip_model):
     """Opt-in persistent-state mode (BASELINE configs[4], SURVEY.md 8(b) Ownership): the state stays in the
     engine's NHWC buffer between calls == re-feeding the returned state, bit for bit; a foreign tensor is
