@@ -7,7 +7,7 @@
 set -e
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r5final
-if [ -z "$ONLY_BENCH" ]; then rm -rf $O; fi      # ONLY_BENCH=1: just the bench lines again (bench.py changed, kernels did not)
+if [ -z "$ONLY_BENCH" ] && [ -z "$ONLY_SET" ]; then rm -rf $O; fi      # ONLY_BENCH=1: just the bench lines again (bench.py changed, kernels did not)
 mkdir -p $O
 B="--no-cpu-baseline --no-extra --no-roofline"
 run_set() {   # $1 = prec, $2 = clips, $3 = label, $4 = file tag (bench.py _wl_tag), $5 = 1: also the SQ-counter passes, $6... = extra bench arguments
@@ -35,16 +35,18 @@ run_set() {   # $1 = prec, $2 = clips, $3 = label, $4 = file tag (bench.py _wl_t
   cp $O/r5_hbm_traffic_$T.json $O/r5_kernel_stats_$T.json $O/r5_kernel_stats_${T}_lanes0.json profiles/     # so that the bench line below can quote them
   rm -rf $O/f_$T $O/w_$T $O/kt_$T/kt_kernel_trace.csv $O/kl_$T/kl_kernel_trace.csv $O/sa_$T $O/sb_$T
 }
+# ONLY_SET=<file tag>: re-collect one workload (its plan changed, the kernels did not) and its bench line
+want() { [ -z "$ONLY_SET" ] || [ "$ONLY_SET" = "$1" ]; }
 if [ -z "$ONLY_BENCH" ]; then
-run_set f32 1 "bench.py (configs[1]: 360x640, 1 clip x 8 frames, f32)" f32_c1 1
-run_set f32 8 "bench.py --clips 8 (one GPU's share of configs[3]: 360x640, 8 clips x 8 frames, f32)" f32_c8 0
-run_set f16x3 8 "bench.py --prec f16x3 --clips 8 (configs[2]: 360x640, 8 clips x 8 frames, split-fp16 MFMA)" f16x3_c8 1
-run_set f32 4 "bench.py --height 720 --width 1280 --frames 16 --clips 4 --persistent-state 1 (configs[4])" f32_c4_720x1280_t16 0 --height 720 --width 1280 --frames 16 --persistent-state 1 --steps 5 --warmup 2
+want f32_c1 && run_set f32 1 "bench.py (configs[1]: 360x640, 1 clip x 8 frames, f32)" f32_c1 1
+want f32_c8 && run_set f32 8 "bench.py --clips 8 (one GPU's share of configs[3]: 360x640, 8 clips x 8 frames, f32)" f32_c8 0
+want f16x3_c8 && run_set f16x3 8 "bench.py --prec f16x3 --clips 8 (configs[2]: 360x640, 8 clips x 8 frames, split-fp16 MFMA)" f16x3_c8 1
+want f32_c4_720x1280_t16 && run_set f32 4 "bench.py --height 720 --width 1280 --frames 16 --clips 4 --persistent-state 1 (configs[4])" f32_c4_720x1280_t16 0 --height 720 --width 1280 --frames 16 --persistent-state 1 --steps 5 --warmup 2
 fi
 cd $R
-python3 bench.py > $O/r5_bench_default.json 2> $O/r5_bench_default.err
-python3 bench.py --clips 8 --no-extra --no-cpu-baseline > $O/r5_bench_f32_c8.json 2> $O/r5_bench_f32_c8.err
-python3 bench.py --prec f16x3 --clips 8 --no-extra --no-cpu-baseline > $O/r5_bench_f16x3_c8.json 2> $O/r5_bench_f16x3_c8.err
-python3 bench.py --prec f16x3 --no-extra --no-cpu-baseline > $O/r5_bench_f16x3_c1.json 2> $O/r5_bench_f16x3_c1.err
-python3 bench.py --height 720 --width 1280 --frames 16 --clips 4 --persistent-state 1 --steps 5 --warmup 2 --no-extra --no-cpu-baseline > $O/r5_bench_720p_c4_t16.json 2> $O/r5_bench_720p_c4_t16.err
+want f32_c1 && python3 bench.py > $O/r5_bench_default.json 2> $O/r5_bench_default.err
+want f32_c8 && python3 bench.py --clips 8 --no-extra --no-cpu-baseline > $O/r5_bench_f32_c8.json 2> $O/r5_bench_f32_c8.err
+want f16x3_c8 && python3 bench.py --prec f16x3 --clips 8 --no-extra --no-cpu-baseline > $O/r5_bench_f16x3_c8.json 2> $O/r5_bench_f16x3_c8.err
+want f16x3_c8 && python3 bench.py --prec f16x3 --no-extra --no-cpu-baseline > $O/r5_bench_f16x3_c1.json 2> $O/r5_bench_f16x3_c1.err
+want f32_c4_720x1280_t16 && python3 bench.py --height 720 --width 1280 --frames 16 --clips 4 --persistent-state 1 --steps 5 --warmup 2 --no-extra --no-cpu-baseline > $O/r5_bench_720p_c4_t16.json 2> $O/r5_bench_720p_c4_t16.err
 ls $O
