@@ -188,12 +188,13 @@ def kernel_rooflines(eng, prec, iters=5):
         # slower on random operands than on half-zero ones)
         eng.run_ops(0, i)
         ms = min(eng.time_ops(i, i + 1, iters), eng.time_ops(i, i + 1, iters))
+        mp = m.get("prec") or prec          # (an op may run in another precision than the plan's: the exact-fp32 Winograd steps of an f16x3 plan)
         if m["kind"].startswith("conv"):
-            key = kernel_symbol(prec, m["tile"], 9 if m["kind"] == "conv3" else 1, m.get("streamk", 0), m.get("split", False))
+            key = kernel_symbol(mp, m["tile"], 9 if m["kind"] == "conv3" else 1, m.get("streamk", 0), m.get("split", False))
             if m.get("dwproj"):
-                key = "dwproj_kernel<%d, %s, 0>" % (PREC_ID[prec], {256: "2, 4, 2, 2", 128: "2, 4, 2, 1", 64: "4, 2, 1, 1", 32: "4, 1, 1, 1"}[m["dwproj"]])
+                key = "dwproj_kernel<%d, %s, 0>" % (PREC_ID[mp], {256: "2, 4, 2, 2", 128: "2, 4, 2, 1", 64: "4, 2, 1, 1", 32: "4, 1, 1, 1"}[m["dwproj"]])
             elif m.get("fused_dw"):
-                key = "conv_gemm_kernel<%s, true>" % (H16_INST[m["tile"]] % (PREC_ID[prec], 1))
+                key = "conv_gemm_kernel<%s, true>" % (H16_INST[m["tile"]] % (PREC_ID[mp], 1))
         elif m["kind"] in ("dw", "dw_dot", "fused_ir"):
             key = m["kernel"]                  # uavsal_dw_variant / the fused block instance the library launches
         else:
@@ -201,7 +202,7 @@ def kernel_rooflines(eng, prec, iters=5):
         if os.environ.get("UAVSAL_BENCH_OPS"):
             print("[op %3d] %-28s %-8s %9.1f us %8.1f GB/s %8.2f TFLOP/s" % (
                 i, m["name"], key[-22:], ms * 1e3, m["bytes"] / ms / 1e6, m["flops"] / ms / 1e9), file=sys.stderr)
-        g = groups.setdefault(key, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0, "kind": m["kind"], "unfused_bytes": 0.0})
+        g = groups.setdefault(key, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0, "kind": m["kind"], "unfused_bytes": 0.0, "prec": mp})
         g["unfused_bytes"] += m.get("unfused_bytes", 0.0)
         g["ms"] += ms
         g["flops"] += m["flops"]
@@ -211,6 +212,7 @@ def kernel_rooflines(eng, prec, iters=5):
 
 
 def roofline_obj(name, g, prec):
+    prec = g.get("prec") or prec
     sec = g["ms"] * 1e-3
     if g["kind"].startswith("conv"):
         ach = g["flops"] / sec / 1e12

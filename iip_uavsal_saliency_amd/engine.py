@@ -758,6 +758,7 @@ class Engine:
             d.err = self._err
             m_ = self.ops_meta[-1]
             m_["split"], m_["tile"], m_["streamk"], m_["dwproj"] = False, int(self.lib.uavsal_conv_tile(C.byref(d))), 0, 0
+            m_["prec"] = "f32"
             self._add(self.lib.uavsal_plan_add_conv, d, "plan_add_conv(%s)" % nm_)
         self._meta(kind="wino_out", name=name + ".xout", flops=0.0, bytes=4.0 * (float(pp) * tiles * cout + n * hw * cout))
         self._touch(mm, out, *(twa or ()), *((a,) if twa is not None else ()))
