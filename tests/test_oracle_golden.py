@@ -190,6 +190,29 @@ def test_mat_writer_round_trip_and_layout(tmp_path):
     if os.path.exists(ref):      # same superblock / root-group prefix as a file hdf5storage wrote (up to the end-of-file address)
         r = open(ref, "rb").read()
         assert r[512:512 + 40] == raw[512:512 + 40] and r[512 + 48:512 + 96 + 40] == raw[512 + 48:512 + 96 + 40]
+    if os.path.exists(ref):
+        # ... and message by message against the dataset header hdf5storage wrote for the reference's own priors file: write the SAME
+        # array under the same name and compare the object-header messages that do not depend on the storage layout (the reference
+        # file is chunked + shuffle + deflate, ours contiguous): datatype (0x03) and the MATLAB_class attribute (0x0c) byte for
+        # byte, the dataspace's (0x01) rank and dimensions, the fill-value message's (0x05) version / defined / size fields
+        def dataset_msgs(p_, name):
+            raw_ = open(p_, "rb").read()
+            h5 = matio._H5(raw_)
+            ent = h5.group_entries(h5.root_btree, h5.root_heap)
+            return [(t, raw_[pos:pos + sz]) for (t, pos, sz) in h5.messages(ent[name])]
+        maps = matio.loadmat(ref)["PriorMaps"]
+        p2 = str(tmp_path / "priors_again.mat")
+        matio.savemat(p2, {"PriorMaps": maps})
+        theirs, ours = dataset_msgs(ref, "PriorMaps"), dataset_msgs(p2, "PriorMaps")
+        first = lambda ms, t: [m for (tt, m) in ms if tt == t][0]
+        assert first(ours, 0x03) == first(theirs, 0x03)
+        cls_theirs = [m for (tt, m) in theirs if tt == 0x0c and b"MATLAB_class" in m][0]
+        assert first(ours, 0x0c) == cls_theirs
+        ds_o, ds_t = first(ours, 0x01), first(theirs, 0x01)
+        assert ds_o[0] == ds_t[0] == 1 and ds_o[1] == ds_t[1] == maps.ndim and ds_o[8:8 + 8 * maps.ndim] == ds_t[8:8 + 8 * maps.ndim]
+        fv_o, fv_t = first(ours, 0x05), first(theirs, 0x05)
+        assert fv_o[0] == fv_t[0] == 2 and fv_o[3] == fv_t[3] == 1 and fv_o[4:8] == fv_t[4:8]
+        assert np.array_equal(matio.loadmat(p2)["PriorMaps"], maps)
     with pytest.raises(ValueError):
         matio.savemat(path, {"x": np.zeros(3, dtype=np.complex64)})
     # an INDEPENDENT reader, where one is installed (none in the build container: the check above against the reference's own
