@@ -797,6 +797,36 @@ def main():
                     "note": "independent requests round-robin on 2 host streams / model replicas; per-request work unchanged"}
             except Exception as e:
                 result["extra_two_requests_in_flight"] = {"error": repr(e)[:200]}
+        if not args.no_extra and (H, W, T, C) == (360, 640, 8, 1):
+            # ONE video, the reference's unit of work (Demo_Test.py:65-95: consecutive groups, the recurrent state carried from
+            # group to group): 24 groups of 8 uint8 frames through stream.predict_video -- frames normalised in the stem, priors
+            # as one broadcast map set, state resident, maps post-processed on the device -- as the reference's loop runs them
+            # (one after the other) and with the groups two deep in flight (`overlap=True`: only a group's recurrence waits for the
+            # previous group).  Same maps, bit for bit; informative only -- `value` above is one independent request at a time
+            try:
+                from iip_uavsal_saliency_amd.stream import predict_video
+                log("extra: one video of 24 groups x 8 frames, sequential and overlapped")
+                u8 = torch.from_numpy(synth.synth_frames_u8(8, H, W, 0)).repeat(24, 1, 1, 1).to(device)
+                gp, op_ = cb[0][0, 0], cb[1][0, 0]
+                res_v = {}
+                for ov in (False, True):
+                    predict_video(model, u8[:32], gp, op_, batch_size=1, overlap=ov)          # warm-up (plans, replica)
+                    predict_video(model, u8[:32], gp, op_, batch_size=1, overlap=ov)
+                    torch.cuda.synchronize(device)
+                    t0 = time.perf_counter()
+                    sal = predict_video(model, u8, gp, op_, batch_size=1, overlap=ov)
+                    torch.cuda.synchronize(device)
+                    res_v[ov] = (u8.shape[0] / (time.perf_counter() - t0), sal)
+                result["extra_video_stream"] = {
+                    "workload": "one video, %d frames at %dx%d uint8 in groups of %d, state carried, stream.predict_video (incl. device post-processing), prec=%s" % (
+                        u8.shape[0], H, W, T, args.prec),
+                    "sequential": round(res_v[False][0], 2), "overlapped": round(res_v[True][0], 2), "unit": "frames/s",
+                    "bit_identical": bool(torch.equal(res_v[False][1], res_v[True][1])),
+                    "note": "overlapped: group k + 1's launches in front of its recurrence run under group k's recurrence and decoder "
+                            "(two replicas, two host streams, Engine.run_streamed); priors as one broadcast map set (the caller's form)"}
+                del u8, res_v
+            except Exception as e:
+                result["extra_video_stream"] = {"error": repr(e)[:300]}
         if not args.no_extra:
             # the SAME inputs handed over the way priors.get_bias hands them: the synthetic priors -- like the reference caller's
             # (np.repeat of one prior file over the frames, utils_data.py:466-467, 601-602) -- are one map set for every frame; as

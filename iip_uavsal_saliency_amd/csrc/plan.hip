@@ -251,7 +251,7 @@ extern "C" int uavsal_plan_run(uavsal_plan* p, int first, int last, uavsal_strea
         const int e = run_op(op, s);
         if (e) return e;
     }
-    if (first == 0 && last == n) {
+    if (last == n) {       // the run that ends the plan (its guard op) -- whole, or the second part of a run issued in two ranges
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(main_s, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
         if (cs == hipStreamCaptureStatusNone && p->done) {     // (a captured run is marked by uavsal_plan_graph_launch)

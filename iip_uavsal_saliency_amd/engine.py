@@ -1552,6 +1552,41 @@ class Engine:
                 taps["logits"] = self.logits.clone().view(self.N, 1, self.h, self.w)
         return out, st
 
+    def state_split(self) -> int:
+        """Index of the first op that reads the recurrent state (the recurrence's first step; in resident-state mode nothing in
+        front of it does): ops [0, state_split) of a forward do not depend on the previous forward of the same video."""
+        for i, m in enumerate(self.ops_meta):
+            if m.get("name", "").startswith(("twa.step0", "lstm.step0")):
+                return i
+        raise RuntimeError("plan has no recurrence step")
+
+    def run_streamed(self, x, cb0, cb1, prev: Optional["Engine"] = None, prev_done: Optional[torch.cuda.Event] = None, reset=False):
+        """One group of a VIDEO whose previous group ran (or is still running) on `prev` -- this engine or another replica's --
+        in resident-state mode: everything in front of the recurrence is launched at once, then the launch stream waits for
+        `prev_done`, takes over `prev`'s recurrent state (a device copy of the NHWC state buffer; `reset`: zeros -- the first
+        group, model_convlstm.py:356) and runs the recurrence, the decoder and the guard.  The arithmetic of a group is that of
+        `run` (same plan, same order per lane-less launch): maps are bit-identical to the sequential loop; what changes is that
+        the head of group k + 1 overlaps the tail of group k (Demo_Test.py:75-86 runs them back to back)."""
+        if not (self.persistent and self.inplace):
+            raise RuntimeError("run_streamed needs the resident-state launch-loop plan (model.persistent_state = True, no graph)")
+        lstm = getattr(self.model, "rnn_type", "twa") == "lstm"
+        with torch.cuda.device(self.device):
+            self.check(wait=False)
+            out, _ = self._bind_in_place(x, cb0, cb1, self.h_view, self.c_view, lstm)      # (resident views: nothing is staged)
+            split = self.state_split()
+            L.check(self.lib.uavsal_plan_run(self.plan, 0, split, self._stream()), "plan_run(head)")
+            cur = torch.cuda.current_stream(self.device)
+            if prev_done is not None:
+                cur.wait_event(prev_done)
+            for name in ("h0", "c0") if lstm else ("h0",):
+                mine = self.named[name].t
+                if reset:
+                    mine.zero_()
+                elif prev is not None and prev is not self:
+                    mine.copy_(prev.named[name].t)
+            L.check(self.lib.uavsal_plan_run(self.plan, split, -1, self._stream()), "plan_run(tail)")
+        return out
+
     def check(self, wait=True):
         """Raise if the most recent run reported a device-side error (its outputs were overwritten with NaN).
         `wait=False` only looks when that run is known to have finished."""

@@ -485,7 +485,9 @@ int uavsal_plan_add_fork(uavsal_plan* p, int lane);
 int uavsal_plan_add_join(uavsal_plan* p, int lane);
 int uavsal_plan_enable_lanes(uavsal_plan* p, int on);
 int uavsal_plan_size(const uavsal_plan* p);
-/* launch ops [first, last) in order on `stream` (last < 0: to the end) */
+/* launch ops [first, last) in order on `stream` (last < 0: to the end).  Lanes are honoured when the whole plan runs; a sub-range is
+ * launched flat on `stream`.  A run that reaches the end of the plan -- whole, or the second of two ranges (the streaming driver issues
+ * everything in front of the recurrence, waits for the previous group's state, then the rest) -- is the one uavsal_plan_status reports on. */
 int uavsal_plan_run(uavsal_plan* p, int first, int last, uavsal_stream_t stream);
 /* capture the whole plan into a hipGraph once, then replay it */
 int uavsal_plan_graph_build(uavsal_plan* p, uavsal_stream_t stream);

@@ -712,6 +712,50 @@ def test_predict_video_equals_manual_loop(hip_model, oracle):
         assert np.array_equal(mat[:, :, 0, :].transpose(2, 0, 1), sal[:5].cpu().numpy())
 
 
+@pytest.mark.parametrize("variant", ["twa", "lstm"])
+def test_predict_video_overlapped_groups_are_bit_identical(hip_model, variant):
+    """`predict_video(overlap=True)`: the groups of one video two deep in flight on two replicas -- everything in front of the
+    recurrence of group k + 1 is launched under the tail of group k, only the recurrence waits for (and takes over) the previous
+    group's state (`Engine.run_streamed`).  Same maps as the sequential loop of Demo_Test.py:75-86, bit for bit, over 7 groups
+    (state carried through both replicas several times); needs the resident state and whole groups."""
+    from iip_uavsal_saliency_amd import UAVSAL_LSTM, stream
+    m = hip_model
+    if variant == "lstm":
+        m = UAVSAL_LSTM(time_dims=4)
+        synth.load_synth_weights(m, 0)
+        m = m.cuda().eval()
+    m.time_dims, m.precision = 4, "f32"
+    frames = torch.from_numpy(synth.synth_frames_u8(28, 96, 160, 3)).cuda()
+    g = torch.from_numpy(synth.gauss_priors(1, 12, 20))[0].cuda()
+    o = torch.from_numpy(synth.ob_priors(1, 12, 20, seed=3))[0].cuda()
+    if variant == "lstm":      # ((h, c) carried: against a manual loop over forward())
+        a_sal, a_maps = stream.predict_video(m, frames, g, o, batch_size=1, return_maps=True, overlap=True)
+        b_sal, b_maps = stream.predict_video(m, frames, g, o, batch_size=1, return_maps=True, overlap=True)
+        ref, st = [], None
+        for k in range(7):
+            x = frames[4 * k:4 * k + 4]
+            out, s2 = m(x, [g[None].expand(4, -1, -1, -1), o[None].expand(4, -1, -1, -1)], st)
+            st = [(s2[0].clone(), s2[1].clone())]
+            ref.append(out.clone())
+        assert torch.equal(a_maps, torch.cat(ref, 0)) and torch.equal(a_maps, b_maps) and torch.equal(a_sal, b_sal)
+        c_sal = stream.predict_video(m, frames, g, o, batch_size=1, overlap=False)      # the one-after-the-other loop carries (h, c) too
+        assert torch.equal(c_sal, a_sal)
+        return
+    seq_sal, seq_maps = stream.predict_video(m, frames, g, o, batch_size=1, return_maps=True, overlap=False)
+    ov_sal, ov_maps = stream.predict_video(m, frames, g, o, batch_size=1, return_maps=True, overlap=True)
+    auto_sal = stream.predict_video(m, frames, g, o, batch_size=1)            # default: overlapped wherever it applies
+    assert torch.equal(auto_sal, seq_sal)
+    assert torch.equal(seq_maps, ov_maps) and torch.equal(seq_sal, ov_sal) and bool(torch.isfinite(ov_maps).all().item())
+    ov2 = stream.predict_video(m, frames[:24], g, o, batch_size=2, overlap=True)          # groups of 2 x time_dims frames
+    seq2 = stream.predict_video(m, frames[:24], g, o, batch_size=2, overlap=False)
+    assert torch.equal(stream.predict_video(m, frames[:28], g, o, batch_size=2), stream.predict_video(m, frames[:28], g, o, batch_size=2, overlap=False))
+    assert torch.equal(ov2, seq2)
+    with pytest.raises(RuntimeError):          # a shorter last group runs on another plan: not in the overlapped form
+        stream.predict_video(m, frames[:28], g, o, batch_size=2, overlap=True)
+    with pytest.raises(RuntimeError):
+        stream.predict_video(m, frames, g, o, batch_size=1, overlap=True, persistent_state=False)
+
+
 @pytest.mark.parametrize("prec", ["f32", "f16x3"])
 def test_lstm_variant_vs_reference_golden_and_oracle(golden_dir, prec):
     """UAVSAL_LSTM (reference model.py:960-1076): ConvLSTM recurrence, (h, c) carried across two calls."""
