@@ -745,6 +745,11 @@ def test_predict_video_overlapped_groups_are_bit_identical(hip_model, variant):
     ov_sal, ov_maps = stream.predict_video(m, frames, g, o, batch_size=1, return_maps=True, overlap=True)
     auto_sal = stream.predict_video(m, frames, g, o, batch_size=1)            # default: overlapped wherever it applies
     assert torch.equal(auto_sal, seq_sal)
+    m.arena_debug = True          # the two ranges of a plan with every released activation NaN-filled behind its last use
+    try:
+        assert torch.equal(stream.predict_video(m, frames, g, o, batch_size=1, overlap=True), seq_sal)
+    finally:
+        m.arena_debug = False
     assert torch.equal(seq_maps, ov_maps) and torch.equal(seq_sal, ov_sal) and bool(torch.isfinite(ov_maps).all().item())
     ov2 = stream.predict_video(m, frames[:24], g, o, batch_size=2, overlap=True)          # groups of 2 x time_dims frames
     seq2 = stream.predict_video(m, frames[:24], g, o, batch_size=2, overlap=False)
