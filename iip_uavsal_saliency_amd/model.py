@@ -301,7 +301,7 @@ class UAVSal(nn.Module):
             elif self._weights_version() != self._wversion:      # in-place ops on the parameters (no_grad), optimizer steps
                 # (edits through `param.data` do NOT bump the version counter: call invalidate_engines() after those)
                 self._drop_engines()
-                return self._engine(device, n_seq, seq_len, H, W, ctx_mode, taps, in_dtype, sync_default)
+                return self._engine(device, n_seq, seq_len, H, W, ctx_mode, taps, in_dtype, sync_default, static_priors)
         key = (str(device), n_seq, seq_len, H, W, self.time_dims if ctx_mode == "tile" else seq_len,
                ctx_mode, self.precision, bool(taps), in_dtype, bool(self.use_graph), self.rnn_type, self.fuse_dw, bool(self.use_lanes),
                bool(self.stream_k), bool(self.persistent_state), tuple(getattr(self, "_sk_debug", (0, 0))),

@@ -32,8 +32,20 @@ def _predict_overlapped(model, frames_u8, gauss_prior, ob_prior, group, steps, d
     the recurrence -- backbone, SRF-Net, ST blocks, prior fusion, the hoisted half of the gate convolution: 3.5 of a group's 4.2 ms
     at 8 frames -- does not depend on the previous group and is launched at once; the recurrence waits for the previous group's
     last launch and takes over its state (`Engine.run_streamed`).  The maps are those of the sequential loop, bit for bit."""
-    models = [model, model.replica()]
-    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    # the second handle is kept on the model between videos (its launch plans cost ~50 ms to build); it follows the model's
+    # current settings, and loses its plans when the model's packed weights were dropped (load_state_dict, in-place edits)
+    rep = model.__dict__.get("_stream_replica")
+    if rep is None:
+        rep = model.replica()
+    else:
+        engines = rep._engines if rep.__dict__.get("_wshared") is model.__dict__.get("_wshared") else None
+        rep.__dict__.update({k: v for k, v in model.__dict__.items() if k != "_stream_replica"})
+        rep._engines = engines if engines is not None else type(model._engines)()
+    model.__dict__["_stream_replica"] = rep
+    models = [model, rep]
+    streams = model.__dict__.get("_stream_streams")
+    if streams is None or streams[0].device != torch.device(dev):
+        streams = model.__dict__["_stream_streams"] = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
     caller = torch.cuda.current_stream(dev)
     maps, prev_eng, prev_done = [], None, None
     for s_ in streams:

@@ -755,6 +755,17 @@ def test_predict_video_overlapped_groups_are_bit_identical(hip_model, variant):
     seq2 = stream.predict_video(m, frames[:24], g, o, batch_size=2, overlap=False)
     assert torch.equal(stream.predict_video(m, frames[:28], g, o, batch_size=2), stream.predict_video(m, frames[:28], g, o, batch_size=2, overlap=False))
     assert torch.equal(ov2, seq2)
+    # the second handle is kept on the model between videos and must follow an in-place weight edit (both handles rebuild their plans
+    # from the new values: same maps as the one-after-the-other loop, different from before)
+    with torch.no_grad():
+        m.conv_out_st.conv[3].bias.add_(0.5)
+    try:
+        ov3 = stream.predict_video(m, frames, g, o, batch_size=1, overlap=True)
+        seq3 = stream.predict_video(m, frames, g, o, batch_size=1, overlap=False)
+        assert torch.equal(ov3, seq3) and bool((ov3 != ov_sal).any().item())
+    finally:
+        with torch.no_grad():
+            m.conv_out_st.conv[3].bias.sub_(0.5)
     with pytest.raises(RuntimeError):          # a shorter last group runs on another plan: not in the overlapped form
         stream.predict_video(m, frames[:28], g, o, batch_size=2, overlap=True)
     with pytest.raises(RuntimeError):
