@@ -291,17 +291,22 @@ class UAVSal(nn.Module):
         Never decided from the values: materialised copies (`np.repeat`, `.repeat`, `.contiguous()`) take the general plan."""
         return all(all(t.shape[d] == 1 or t.stride(d) == 0 for d in range(frame_dims)) for t in cb)
 
+    def _check_weights(self):
+        """Drops the plans and the packed device weights when a parameter or buffer was modified since they were packed."""
+        if not self.check_weight_versions:
+            return
+        if self._wversion is not None and self._weights_version() != self._wversion:
+            # in-place ops on the parameters (no_grad), optimizer steps
+            # (edits through `param.data` do NOT bump the version counter: call invalidate_engines() after those)
+            self._drop_engines()
+        if self._wversion is None:
+            self._wtensors = [t for k, t in self.state_dict(keep_vars=True).items()
+                              if not k.endswith("num_batches_tracked")]
+            self._wversion = self._weights_version()
+
     def _engine(self, device, n_seq, seq_len, H, W, ctx_mode, taps=False, in_dtype=torch.float32, sync_default=True, static_priors=False):
         from .engine import Engine
-        if self.check_weight_versions:
-            if self._wversion is None:
-                self._wtensors = [t for k, t in self.state_dict(keep_vars=True).items()
-                                  if not k.endswith("num_batches_tracked")]
-                self._wversion = self._weights_version()
-            elif self._weights_version() != self._wversion:      # in-place ops on the parameters (no_grad), optimizer steps
-                # (edits through `param.data` do NOT bump the version counter: call invalidate_engines() after those)
-                self._drop_engines()
-                return self._engine(device, n_seq, seq_len, H, W, ctx_mode, taps, in_dtype, sync_default, static_priors)
+        self._check_weights()
         key = (str(device), n_seq, seq_len, H, W, self.time_dims if ctx_mode == "tile" else seq_len,
                ctx_mode, self.precision, bool(taps), in_dtype, bool(self.use_graph), self.rnn_type, self.fuse_dw, bool(self.use_lanes),
                bool(self.stream_k), bool(self.persistent_state), tuple(getattr(self, "_sk_debug", (0, 0))),

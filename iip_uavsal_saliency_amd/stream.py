@@ -8,6 +8,7 @@ maps are resized / normalised / quantised by `uavsal_postprocess`."""
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional
 
 import torch
@@ -26,26 +27,53 @@ def save_salmap(path: str, sal_u8: torch.Tensor, save_frames: Optional[int] = No
     matio.savemat(path, {"salmap": a[:, :, :, None].transpose(1, 2, 3, 0)})
 
 
+def _host_streams(dev, n):
+    """`n` host streams that really run side by side.  The HIP runtime multiplexes the streams of one priority onto
+    GPU_MAX_HW_QUEUES (default 4) hardware queues, a stream taking the least used one when it is created; two streams on one
+    queue execute strictly in submission order.  With the plans' lane streams and torch's pool around, two ordinary streams can
+    end up on one queue, and the overlap is gone without a word (measured: 2077 frames/s -> 1851, below the 1888 of the plain
+    loop; profiles/r5_experiments.md).  High-priority streams draw from a queue pool of their own, which nothing else in this
+    package uses; consecutive ones get different queues."""
+    prio = int(os.environ.get("UAVSAL_HOST_STREAM_PRIORITY", "-1"))
+    return [torch.cuda.Stream(dev, priority=prio) for _ in range(n)]
+
+
+_CACHE_KEYS = ("_stream_replicas", "_stream_streams")
+
+
+def _inflight_replicas(model, n):
+    """`n` handles on `model`'s weights for forwards that overlap on the GPU, cached on the model.  They run WITHOUT lanes: a
+    plan's lanes are worth +0.8 % by themselves (fp32, one clip), but with two plans in flight their five streams each compete
+    with the host streams for four hardware queues, and the overlap varies between 1884 and 2059 frames/s with the order things
+    were created in; lane-less plans give 2075-2087 in every order (profiles/r5_experiments.md).  Same kernels, same order per
+    buffer: the maps do not change."""
+    model._check_weights()                    # (the model itself may never run: its handles must not inherit stale weights)
+    reps = model.__dict__.get("_stream_replicas") or []
+    while len(reps) < n:
+        reps.append(model.replica())
+    for rep in reps:
+        engines = rep._engines if rep.__dict__.get("_wshared") is model.__dict__.get("_wshared") else None
+        rep.__dict__.update({k: v for k, v in model.__dict__.items() if k not in _CACHE_KEYS})
+        rep._engines = engines if engines is not None else type(model._engines)()
+        rep.use_lanes = False
+        for k in _CACHE_KEYS:
+            rep.__dict__.pop(k, None)
+    model.__dict__["_stream_replicas"] = reps
+    return reps[:n]
+
+
 @torch.no_grad()
 def _predict_overlapped(model, frames_u8, gauss_prior, ob_prior, group, steps, dev):
     """The groups of ONE video two deep in flight: group k runs on replica k % 2 and host stream k % 2; everything in front of
     the recurrence -- backbone, SRF-Net, ST blocks, prior fusion, the hoisted half of the gate convolution: 3.5 of a group's 4.2 ms
     at 8 frames -- does not depend on the previous group and is launched at once; the recurrence waits for the previous group's
     last launch and takes over its state (`Engine.run_streamed`).  The maps are those of the sequential loop, bit for bit."""
-    # the second handle is kept on the model between videos (its launch plans cost ~50 ms to build); it follows the model's
-    # current settings, and loses its plans when the model's packed weights were dropped (load_state_dict, in-place edits)
-    rep = model.__dict__.get("_stream_replica")
-    if rep is None:
-        rep = model.replica()
-    else:
-        engines = rep._engines if rep.__dict__.get("_wshared") is model.__dict__.get("_wshared") else None
-        rep.__dict__.update({k: v for k, v in model.__dict__.items() if k != "_stream_replica"})
-        rep._engines = engines if engines is not None else type(model._engines)()
-    model.__dict__["_stream_replica"] = rep
-    models = [model, rep]
+    # the two handles are kept on the model between videos (their launch plans cost ~50 ms to build); they follow the model's
+    # current settings, and lose their plans when the model's packed weights were dropped (load_state_dict, in-place edits)
+    models = _inflight_replicas(model, 2)
     streams = model.__dict__.get("_stream_streams")
     if streams is None or streams[0].device != torch.device(dev):
-        streams = model.__dict__["_stream_streams"] = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+        streams = model.__dict__["_stream_streams"] = _host_streams(dev, 2)
     caller = torch.cuda.current_stream(dev)
     maps, prev_eng, prev_done = [], None, None
     for s_ in streams:
@@ -141,14 +169,16 @@ def predict_video(model, frames_u8: torch.Tensor, gauss_prior: torch.Tensor, ob_
 
 class RequestPipeline:
     """Independent requests (clips of DIFFERENT videos: no carried state between them) kept `streams` deep in
-    flight: request k runs on host stream k % streams through its own model replica, so the tail of one forward
-    (ConvTWA steps, decoder) overlaps the head of the next.  Per-request arithmetic and results are unchanged
-    (bitwise: tests/test_hip_e2e.py); one request's latency grows, throughput rises -- 1505 -> 1607 frames/s fp32,
-    2272 -> 2614 f16x3 at one 8-frame clip per request, two streams (profiles/r2_pipeline_probe.log).
-    Requests of the SAME video must stay on one replica in order (their state is a true dependency)."""
+    flight: request k runs on host stream k % streams through its own handle on the model (`_inflight_replicas`: same weights,
+    own lane-less launch plans), so the tail of one forward (ConvTWA steps, decoder) overlaps the head of the next.
+    Per-request arithmetic and results are unchanged (bitwise: tests/test_hip_e2e.py); one request's latency grows,
+    throughput rises -- 1890 -> 2068-2087 frames/s fp32 at one 8-frame clip per request, two streams
+    (profiles/r5_experiments.md; round 2: 1505 -> 1607).
+    Requests of the SAME video are ordered by their state: `predict_video` overlaps those up to the recurrence."""
 
     def __init__(self, model, streams: int = 2):
-        self.models = [model] + [model.replica() for _ in range(max(1, int(streams)) - 1)]
+        self.model = model
+        self.models = _inflight_replicas(model, max(1, int(streams)))      # lane-less handles, see there
         self._streams = None
         self._k = 0
 
@@ -158,8 +188,10 @@ class RequestPipeline:
         replica's stream: wait for `event` (or call `synchronize()`) before using them on another stream."""
         dev = x.device
         if self._streams is None:
-            self._streams = [torch.cuda.Stream(dev) for _ in self.models]
+            self._streams = _host_streams(dev, len(self.models))
         i = self._k % len(self.models)
+        if self._k % len(self.models) == 0:
+            self.models = _inflight_replicas(self.model, len(self.models))      # follow the model's settings / weight edits
         self._k += 1
         s = self._streams[i]
         s.wait_stream(torch.cuda.current_stream(dev))        # inputs were produced on the caller's stream

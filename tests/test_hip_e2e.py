@@ -852,9 +852,27 @@ def test_request_pipeline_equals_sequential_calls(prec):
         reqs.append((x, cb, st))
     want = [m.forward_clips(x, cb, st) for x, cb, st in reqs]
     torch.cuda.synchronize(dev)
+    w0 = want[0][0].clone()
     pipe = RequestPipeline(m, streams=2)
     assert pipe.models[1]._wshared is m._wshared and pipe.models[1]._engines is not m._engines
     got = [pipe.forward_clips(x, cb, st) for x, cb, st in reqs]
     pipe.synchronize()
     for (wo, ws), (go, gs, _) in zip(want, got):
         assert torch.equal(wo, go) and torch.equal(ws, gs)
+    # the in-flight handles run without lanes (stream._inflight_replicas) and keep their plans from round to round
+    assert all(not r.use_lanes for r in pipe.models) and m.use_lanes
+    plans = [next(iter(r._engines.values())) for r in pipe.models]
+    got = [pipe.forward_clips(x, cb, st) for x, cb, st in reqs[:2]]
+    pipe.synchronize()
+    assert [next(iter(r._engines.values())) for r in pipe.models] == plans
+    # an in-place weight edit reaches the handles although the model itself does not run in between
+    with torch.no_grad():
+        next(m.parameters()).mul_(0.5)
+    got = [pipe.forward_clips(x, cb, st) for x, cb, st in reqs[:3]]
+    pipe.synchronize()
+    assert [next(iter(r._engines.values())) for r in pipe.models] != plans
+    want = [m.forward_clips(x, cb, st) for x, cb, st in reqs[:3]]
+    torch.cuda.synchronize(dev)
+    for (wo, ws), (go, gs, _) in zip(want, got):
+        assert torch.equal(wo, go) and torch.equal(ws, gs)
+    assert not torch.equal(want[0][0], w0)
