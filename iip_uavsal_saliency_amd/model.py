@@ -250,9 +250,25 @@ class UAVSal(nn.Module):
         part of the chip idle in (the ConvTWA steps, the small backbone maps): `stream.RequestPipeline`,
         tools/pipeline_probe.py.  Settings are copied as they are now."""
         import copy
-        r = copy.copy(self)
-        r._engines = OrderedDict()
+        r = copy.copy(self)                      # parameters, modules and settings by reference; no runtime state (__getstate__)
+        r._wshared, r._wversion = self._wshared, self._wversion
+        if "_wtensors" in self.__dict__:
+            r._wtensors = self._wtensors
         return r
+
+    _RUNTIME_STATE = ("_engines", "_wshared", "_wversion", "_wtensors", "_stream_replicas", "_stream_streams")
+
+    def __getstate__(self):
+        """`torch.save(model)` (the form of the reference's checkpoints, model.py:339), `pickle` and `copy.deepcopy` carry the
+        parameters, buffers and settings -- never launch plans, packed device weights or streams, which are handles of this
+        process; the copy packs and records its own at its first call."""
+        return {k: v for k, v in self.__dict__.items() if k not in self._RUNTIME_STATE}
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._engines = OrderedDict()
+        self._wshared = {}
+        self._wversion = None
 
     def _drop_engines(self):
         self._engines = OrderedDict()

@@ -876,3 +876,34 @@ def test_request_pipeline_equals_sequential_calls(prec):
     for (wo, ws), (go, gs, _) in zip(want, got):
         assert torch.equal(wo, go) and torch.equal(ws, gs)
     assert not torch.equal(want[0][0], w0)
+
+
+@pytest.mark.gpu
+def test_deepcopy_and_whole_model_save_after_a_forward():
+    """A model that has run (plans recorded, weights packed, stream handles cached) can be deep-copied and saved whole, as the
+    reference saves its checkpoints (model.py:339); the copy builds its own plans and gives the same maps."""
+    import copy
+    import io
+    from iip_uavsal_saliency_amd import UAVSal, synth
+    from iip_uavsal_saliency_amd.stream import predict_video
+    dev = torch.device("cuda:0")
+    m = UAVSal(time_dims=4)
+    synth.load_synth_weights(m, 0)
+    m = m.to(dev).eval()
+    g = torch.Generator().manual_seed(11)
+    x = torch.rand((8, 3, 96, 160), generator=g).to(dev)
+    cb = [torch.rand((8, 8, 12, 20), generator=g).to(dev), torch.rand((8, 20, 12, 20), generator=g).to(dev)]
+    want, wst = m(x, cb, None)
+    u8 = (torch.rand((16, 3, 96, 160), generator=g) * 255).to(torch.uint8).to(dev)
+    sal = predict_video(m, u8, cb[0][0], cb[1][0], batch_size=1)          # overlapped: replicas and streams cached on the model
+    assert "_stream_replicas" in m.__dict__
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    buf.seek(0)
+    for d in (copy.deepcopy(m), torch.load(buf, weights_only=False)):
+        assert len(d._engines) == 0 and "_stream_replicas" not in d.__dict__
+        got, gst = d(x, cb, None)
+        assert torch.equal(got, want) and torch.equal(gst[0], wst[0])
+        assert torch.equal(predict_video(d, u8, cb[0][0], cb[1][0], batch_size=1), sal)
+    got, _ = m(x, cb, None)                   # the original keeps working
+    assert torch.equal(got, want)

@@ -714,3 +714,33 @@ def test_committed_bench_line_carries_the_contract_fields():
         assert r[k]["value"] > 0 and r[k]["max_abs_map_vs_cpu_ref"] <= 1e-3 and r[k]["cpu_oracle_frames_per_s"] > 0 and r[k]["first_call_ms"] > 0
     assert r["first_call_ms"] > 0 and r["activation_arena"]["arena_mb"] < 0.25 * r["activation_arena"]["unshared_mb"]
     assert len(r["scaling_reference"]["windows_ms_per_step"]) == 3 and r["scaling_reference"]["steps"] == r["steps"]
+
+
+def test_model_copies_carry_parameters_and_settings_never_runtime_handles():
+    """`torch.save(model)` (how the reference stores its checkpoints, model.py:339), pickle and deepcopy: parameters and settings
+    travel, launch plans / packed device weights / streams (process-local handles) do not; `replica()` shares the packed weights."""
+    import copy
+    import ctypes
+    import io
+    from iip_uavsal_saliency_amd import UAVSal, UAVSAL_LSTM, synth
+    for cls in (UAVSal, UAVSAL_LSTM):
+        m = cls(time_dims=4)
+        synth.load_synth_weights(m, 0)
+        m.eval()
+        m._engines["k"] = ctypes.c_void_p(1234)              # what a recorded plan holds: not picklable, not copyable
+        m._wshared["cuda:0"] = {"w": ctypes.c_void_p(5)}
+        m.__dict__["_stream_replicas"] = [m.replica()]
+        m.precision, m.persistent_state = "f16x3", True
+        buf = io.BytesIO()
+        torch.save(m, buf)
+        buf.seek(0)
+        for d in (copy.deepcopy(m), torch.load(buf, weights_only=False)):
+            assert type(d) is cls and not d.training
+            assert len(d._engines) == 0 and d._wshared == {} and d._wversion is None and "_stream_replicas" not in d.__dict__
+            assert d.precision == "f16x3" and d.persistent_state is True
+            sd, sm = d.state_dict(), m.state_dict()
+            assert list(sd) == list(sm) and all(torch.equal(sd[k], sm[k]) for k in sm)
+            assert next(d.parameters()).data_ptr() != next(m.parameters()).data_ptr()
+        r = m.replica()
+        assert r._wshared is m._wshared and len(r._engines) == 0
+        assert next(r.parameters()).data_ptr() == next(m.parameters()).data_ptr()
