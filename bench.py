@@ -204,6 +204,7 @@ def kernel_rooflines(eng, prec, iters=5):
                 i, m["name"], key[-22:], ms * 1e3, m["bytes"] / ms / 1e6, m["flops"] / ms / 1e9), file=sys.stderr)
         g = groups.setdefault(key, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0, "kind": m["kind"], "unfused_bytes": 0.0, "prec": mp})
         g["unfused_bytes"] += m.get("unfused_bytes", 0.0)
+        g["flops_executed"] = g.get("flops_executed", 0.0) + m.get("flops_executed", 0.0)
         g["ms"] += ms
         g["flops"] += m["flops"]
         g["bytes"] += m["bytes"]
@@ -661,6 +662,12 @@ def main():
             if fmid:
                 fmid["share_of_kernel_time"] = round(fmid["kernel_ms_per_step"] / tot, 3)
                 fmid["frac_mfma"] = round(fmid["tflops_fp32"] / PEAK_TFLOPS["f32"], 4)
+                ex = sum(g["flops_executed"] for k, g in groups.items() if k.startswith("fused_mid"))
+                fmid["tflops_executed"] = round(ex / fmid["kernel_ms_per_step"] / 1e9, 2)
+                fmid["frac_mfma_executed"] = round(fmid["tflops_executed"] / PEAK_TFLOPS["f32"], 4)
+                fmid["executed_note"] = ("MFMA flops the kernel issues: a 4 x 8 output patch expands its whole 6 x 10 halo (64 rows for 32 "
+                                         "outputs) and 23 rows are covered by 6 patch rows -- 1.5-1.57 x the block's own flops; "
+                                         "tflops_fp32 / frac_mfma count the block's flops only")
                 result["roofline_fused_mid"] = fmid
             dwp = dwproj_family(groups, args.prec)
             if dwp:

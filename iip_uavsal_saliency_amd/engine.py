@@ -895,7 +895,10 @@ class Engine:
                                       + ho * wo * blk.hidden * (9 + out.c)),
                    bytes=4.0 * x.n * (x.h * x.w * x.c + ho * wo * out.c * (2 if blk.use_res_connect else 1)),
                    unfused_bytes=4.0 * x.n * (x.h * x.w * (x.c + (2 * blk.hidden if blk.expand_ratio != 1 else 0))
-                                              + ho * wo * (2 * blk.hidden + out.c)))
+                                              + ho * wo * (2 * blk.hidden + out.c)),
+                   # what the matrix pipe executes in the mid kernel: every 4 x 8 patch expands its whole 6 x 10 halo (64 MFMA
+                   # rows) and projects 32 rows, edge patches included
+                   **({"flops_executed": 2.0 * wgs * blk.hidden * (64 * x.c + 32 * out.c)} if natural else {}))
         self._touch(x, out)
         if out.key is not None:
             self._no_shadow.add(out.key)            # this kernel does not write split shadows
