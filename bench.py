@@ -834,14 +834,24 @@ def main():
                     sal = predict_video(model, u8, gp, op_, batch_size=1, overlap=ov)
                     torch.cuda.synchronize(device)
                     res_v[ov] = (u8.shape[0] / (time.perf_counter() - t0), sal)
+                u8h = u8.cpu().pin_memory()          # the same video from pinned host memory: uploaded group by group on a copy stream
+                predict_video(model, u8h[:32], gp, op_, batch_size=1, overlap=True)
+                torch.cuda.synchronize(device)
+                t0 = time.perf_counter()
+                sal_h = predict_video(model, u8h, gp, op_, batch_size=1, overlap=True)
+                torch.cuda.synchronize(device)
+                fps_h = u8h.shape[0] / (time.perf_counter() - t0)
                 result["extra_video_stream"] = {
+                    "overlapped_from_host": round(fps_h, 2), "from_host_bit_identical": bool(torch.equal(sal_h, res_v[True][1])),
                     "workload": "one video, %d frames at %dx%d uint8 in groups of %d, state carried, stream.predict_video (incl. device post-processing), prec=%s" % (
                         u8.shape[0], H, W, T, args.prec),
                     "sequential": round(res_v[False][0], 2), "overlapped": round(res_v[True][0], 2), "unit": "frames/s",
                     "bit_identical": bool(torch.equal(res_v[False][1], res_v[True][1])),
                     "note": "overlapped: group k + 1's launches in front of its recurrence run under group k's recurrence and decoder "
-                            "(two replicas, two host streams, Engine.run_streamed); priors as one broadcast map set (the caller's form)"}
-                del u8, res_v
+                            "(two replicas, two host streams, Engine.run_streamed); priors as one broadcast map set (the caller's form); "
+                            "overlapped_from_host: the frames start in pinned host memory (PCIe-inclusive) and are uploaded two groups ahead "
+                            "on a copy stream"}
+                del u8, res_v, u8h
             except Exception as e:
                 result["extra_video_stream"] = {"error": repr(e)[:300]}
         if not args.no_extra and (H, W, T, C) == (360, 640, 8, 1):

@@ -38,7 +38,44 @@ def _host_streams(dev, n):
     return [torch.cuda.Stream(dev, priority=prio) for _ in range(n)]
 
 
-_CACHE_KEYS = ("_stream_replicas", "_stream_streams")
+_CACHE_KEYS = ("_stream_replicas", "_stream_streams", "_stream_copy")
+
+
+class _Groups:
+    """The groups of a video as device tensors.  Frames already on the device are sliced; frames in host memory (what a decoder
+    hands over, Demo_Test.py:78-85) are uploaded group by group on a copy stream of their own, `ahead` groups in front of the
+    one being launched, so that the copy of group k + 1 runs under the launches of group k instead of in front of the whole
+    video (pinned memory: asynchronous; pageable memory: the host thread stages it, the GPU keeps computing)."""
+
+    def __init__(self, model, frames_u8, group, steps, dev, ahead=2):
+        self.frames, self.group, self.steps, self.dev, self.ahead = frames_u8, group, steps, dev, ahead
+        self.host = not frames_u8.is_cuda
+        self.pending = {}
+        if self.host:
+            cs = model.__dict__.get("_stream_copy")
+            if cs is None or cs.device != torch.device(dev):
+                cs = model.__dict__["_stream_copy"] = _host_streams(dev, 1)[0]
+            self.copy_stream = cs
+
+    def _fetch(self, i):
+        if i < self.steps and i not in self.pending:
+            with torch.cuda.stream(self.copy_stream):
+                t = self.frames[i * self.group:(i + 1) * self.group].to(self.dev, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self.copy_stream)
+            self.pending[i] = (t, ev)
+
+    def get(self, i, stream=None):
+        """Group `i`, ready on `stream` (default: the current one)."""
+        if not self.host:
+            return self.frames[i * self.group:(i + 1) * self.group]
+        for k in range(i, i + 1 + self.ahead):
+            self._fetch(k)
+        t, ev = self.pending.pop(i)
+        stream = stream or torch.cuda.current_stream(self.dev)
+        stream.wait_event(ev)
+        t.record_stream(stream)
+        return t
 
 
 def _inflight_replicas(model, n):
@@ -63,7 +100,7 @@ def _inflight_replicas(model, n):
 
 
 @torch.no_grad()
-def _predict_overlapped(model, frames_u8, gauss_prior, ob_prior, group, steps, dev):
+def _predict_overlapped(model, groups, gauss_prior, ob_prior, steps, dev):
     """The groups of ONE video two deep in flight: group k runs on replica k % 2 and host stream k % 2; everything in front of
     the recurrence -- backbone, SRF-Net, ST blocks, prior fusion, the hoisted half of the gate convolution: 3.5 of a group's 4.2 ms
     at 8 frames -- does not depend on the previous group and is launched at once; the recurrence waits for the previous group's
@@ -79,9 +116,9 @@ def _predict_overlapped(model, frames_u8, gauss_prior, ob_prior, group, steps, d
     for s_ in streams:
         s_.wait_stream(caller)                    # the frames / priors were produced on the caller's stream
     for i in range(steps):
-        x = frames_u8[i * group:(i + 1) * group]
-        n = x.shape[0]
         m_, s_ = models[i % 2], streams[i % 2]
+        x = groups.get(i, s_)
+        n = x.shape[0]
         with torch.cuda.stream(s_):
             cb = [gauss_prior.unsqueeze(0).expand(n, -1, -1, -1), ob_prior.unsqueeze(0).expand(n, -1, -1, -1)]
             cb0, cb1 = m_._used_cb(cb)
@@ -107,7 +144,8 @@ def predict_video(model, frames_u8: torch.Tensor, gauss_prior: torch.Tensor, ob_
                   persistent_state: bool = True, out_path: Optional[str] = None, save_frames: Optional[int] = None,
                   overlap: Optional[bool] = None):
     """`frames_u8` uint8 `[F,3,H,W]` RGB (already letterboxed to the model size, as
-    preprocess_videos does, utils_data.py:255-287), `gauss_prior` `[8,h,w]`, `ob_prior` `[20,h,w]`
+    preprocess_videos does, utils_data.py:255-287) on the device, or in host memory (pinned for asynchronous copies): host
+    frames are uploaded group by group on a copy stream, two groups ahead of the launches (`_Groups`), `gauss_prior` `[8,h,w]`, `ob_prior` `[20,h,w]`
     float32 (one map set, repeated per frame like get_bias, Demo_Test.py:14-27).
     Frames beyond the last full `time_dims` chunk are dropped (Demo_Test.py:68-70); groups of
     `batch_size * time_dims` frames are pushed through `model.forward` with the state carried
@@ -125,7 +163,9 @@ def predict_video(model, frames_u8: torch.Tensor, gauss_prior: torch.Tensor, ob_
     keep = count_bs * T
     if keep < 2:
         raise RuntimeError("need at least one full chunk of time_dims >= 2 frames")
-    frames_u8 = frames_u8[:keep].to(dev)
+    frames_u8 = frames_u8[:keep]
+    if frames_u8.is_cuda and frames_u8.device != torch.device(dev):
+        frames_u8 = frames_u8.to(dev)
     H, W = frames_u8.shape[2:]
     out_size = out_size or (H, W)
     group = batch_size * T
@@ -144,10 +184,12 @@ def predict_video(model, frames_u8: torch.Tensor, gauss_prior: torch.Tensor, ob_
             if frames_u8.shape[0] % group:
                 raise RuntimeError("overlap=True needs whole groups of batch_size * time_dims frames (a shorter last group runs on "
                                    "another plan)")
-            maps = _predict_overlapped(model, frames_u8, gauss_prior.to(dev), ob_prior.to(dev), group, steps, dev)
+        groups = _Groups(model, frames_u8, group, steps, dev)
+        if overlap:
+            maps = _predict_overlapped(model, groups, gauss_prior.to(dev), ob_prior.to(dev), steps, dev)
             steps = 0
         for i in range(steps):
-            x = frames_u8[i * group:(i + 1) * group]
+            x = groups.get(i)
             n = x.shape[0]
             # one map set for every frame, handed over as a zero-stride view: the model runs its prior nets once per call
             # (model.dedupe_priors) instead of once per frame

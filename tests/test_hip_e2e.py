@@ -907,3 +907,27 @@ def test_deepcopy_and_whole_model_save_after_a_forward():
         assert torch.equal(predict_video(d, u8, cb[0][0], cb[1][0], batch_size=1), sal)
     got, _ = m(x, cb, None)                   # the original keeps working
     assert torch.equal(got, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("overlap", [False, True])
+def test_predict_video_from_host_frames_equals_device_frames(overlap):
+    """Frames in host memory (pinned or pageable) are uploaded group by group on a copy stream ahead of the launches: same maps,
+    bit for bit, as with the whole video resident on the device."""
+    from iip_uavsal_saliency_amd import UAVSal, synth
+    from iip_uavsal_saliency_amd.stream import predict_video
+    dev = torch.device("cuda:0")
+    m = UAVSal(time_dims=4)
+    synth.load_synth_weights(m, 0)
+    m = m.to(dev).eval()
+    g = torch.Generator().manual_seed(77)
+    u8 = (torch.rand((26, 3, 96, 160), generator=g) * 255).to(torch.uint8)          # 6 groups of 4 + 2 dropped frames
+    gp, op_ = torch.rand((8, 12, 20), generator=g), torch.rand((20, 12, 20), generator=g)
+    want, wmaps = predict_video(m, u8.to(dev), gp, op_, batch_size=1, overlap=overlap, return_maps=True)
+    assert want.shape[0] == 24
+    for host in (u8, u8.pin_memory()):
+        got, gmaps = predict_video(m, host, gp, op_, batch_size=1, overlap=overlap, return_maps=True)
+        assert torch.equal(got, want) and torch.equal(gmaps, wmaps)
+    if not overlap:                           # a shorter last group (batch_size 4 -> 16 + 8 frames) from host memory
+        want2 = predict_video(m, u8.to(dev), gp, op_, batch_size=4)
+        assert torch.equal(predict_video(m, u8.pin_memory(), gp, op_, batch_size=4), want2)
