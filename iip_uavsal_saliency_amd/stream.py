@@ -135,7 +135,8 @@ def _predict_overlapped(model, groups, gauss_prior, ob_prior, steps, dev):
         caller.wait_stream(s_)
     for m_ in models:
         m_.check_errors()
-    return maps
+    lstm = getattr(model, "rnn_type", "twa") == "lstm"
+    return maps, ([(prev_eng.h_view, prev_eng.c_view)] if lstm else [prev_eng.h_view])
 
 
 @torch.no_grad()
@@ -154,8 +155,9 @@ def predict_video(model, frames_u8: torch.Tensor, gauss_prior: torch.Tensor, ob_
     `salmap` `[H,W,1,F]` v7.3 .mat file (Demo_Test.py:93-95).
     `overlap`: consecutive groups two deep in flight on two replicas -- only the recurrence of a group waits for the previous
     group (`_predict_overlapped`); same maps, bit for bit, 1833 -> 2006 frames/s on a 192-frame video at 360x640 in groups of 8.
-    None (default): whenever it applies -- resident state, launch-loop plans, at least two groups, no shorter last group;
-    True: insist (raises where it does not apply); False: the reference's one-after-the-other loop."""
+    None (default): whenever it applies -- resident state, launch-loop plans, at least two whole groups (a shorter last group
+    follows them on its own plan, taking over the state); True: insist (raises where it does not apply); False: the reference's
+    one-after-the-other loop."""
     dev = next(model.parameters()).device
     T = model.time_dims
     F = frames_u8.shape[0]
@@ -175,20 +177,19 @@ def predict_video(model, frames_u8: torch.Tensor, gauss_prior: torch.Tensor, ob_
     was = model.persistent_state
     model.persistent_state = bool(persistent_state)
     try:
-        applies = bool(persistent_state) and not model.use_graph and frames_u8.shape[0] % group == 0 and steps >= 2
+        whole = frames_u8.shape[0] // group              # a shorter last group runs on a plan of its own, after the others
+        applies = bool(persistent_state) and not model.use_graph and whole >= 2
         if overlap is None:
             overlap = applies
-        if overlap:
-            if not persistent_state or model.use_graph:
-                raise RuntimeError("overlap=True needs persistent_state=True and the launch-loop plan")
-            if frames_u8.shape[0] % group:
-                raise RuntimeError("overlap=True needs whole groups of batch_size * time_dims frames (a shorter last group runs on "
-                                   "another plan)")
+        if overlap and not applies:
+            raise RuntimeError("overlap=True needs persistent_state=True, the launch-loop plan and at least two whole groups of "
+                               "batch_size * time_dims frames")
         groups = _Groups(model, frames_u8, group, steps, dev)
+        first = 0
         if overlap:
-            maps = _predict_overlapped(model, groups, gauss_prior.to(dev), ob_prior.to(dev), steps, dev)
-            steps = 0
-        for i in range(steps):
+            maps, state = _predict_overlapped(model, groups, gauss_prior.to(dev), ob_prior.to(dev), whole, dev)
+            first = whole
+        for i in range(first, steps):
             x = groups.get(i)
             n = x.shape[0]
             # one map set for every frame, handed over as a zero-stride view: the model runs its prior nets once per call

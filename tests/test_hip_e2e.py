@@ -766,8 +766,11 @@ def test_predict_video_overlapped_groups_are_bit_identical(hip_model, variant):
     finally:
         with torch.no_grad():
             m.conv_out_st.conv[3].bias.sub_(0.5)
-    with pytest.raises(RuntimeError):          # a shorter last group runs on another plan: not in the overlapped form
-        stream.predict_video(m, frames[:28], g, o, batch_size=2, overlap=True)
+    # a shorter last group follows the overlapped whole groups on a plan of its own, with their state
+    assert torch.equal(stream.predict_video(m, frames[:28], g, o, batch_size=2, overlap=True),
+                       stream.predict_video(m, frames[:28], g, o, batch_size=2, overlap=False))
+    with pytest.raises(RuntimeError):          # fewer than two whole groups: nothing to overlap
+        stream.predict_video(m, frames[:12], g, o, batch_size=2, overlap=True)
     with pytest.raises(RuntimeError):
         stream.predict_video(m, frames, g, o, batch_size=1, overlap=True, persistent_state=False)
 
@@ -931,3 +934,28 @@ def test_predict_video_from_host_frames_equals_device_frames(overlap):
     if not overlap:                           # a shorter last group (batch_size 4 -> 16 + 8 frames) from host memory
         want2 = predict_video(m, u8.to(dev), gp, op_, batch_size=4)
         assert torch.equal(predict_video(m, u8.pin_memory(), gp, op_, batch_size=4), want2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cls_name", ["UAVSal", "UAVSAL_LSTM"])
+def test_predict_video_overlaps_whole_groups_and_finishes_a_ragged_tail(cls_name):
+    """46 frames, time_dims 4, batch_size 2: 11 chunks = 5 whole groups of 8 frames (overlapped, two in flight) + one group of 4
+    frames that runs afterwards on its own plan with the state of the fifth -- the maps of the reference's strictly sequential loop."""
+    import iip_uavsal_saliency_amd as pkg
+    from iip_uavsal_saliency_amd import synth
+    from iip_uavsal_saliency_amd.stream import predict_video
+    dev = torch.device("cuda:0")
+    m = getattr(pkg, cls_name)(time_dims=4)
+    synth.load_synth_weights(m, 0)
+    m = m.to(dev).eval()
+    g = torch.Generator().manual_seed(5)
+    u8 = (torch.rand((46, 3, 96, 160), generator=g) * 255).to(torch.uint8)
+    gp, op_ = torch.rand((8, 12, 20), generator=g), torch.rand((20, 12, 20), generator=g)
+    want, wmaps = predict_video(m, u8.to(dev), gp, op_, batch_size=2, overlap=False, return_maps=True)
+    assert want.shape[0] == 44
+    for src in (u8.to(dev), u8.pin_memory()):
+        got, gmaps = predict_video(m, src, gp, op_, batch_size=2, return_maps=True)          # overlap=None: applies (5 whole groups)
+        assert "_stream_replicas" in m.__dict__
+        assert torch.equal(gmaps, wmaps) and torch.equal(got, want)
+    with pytest.raises(RuntimeError, match="at least two whole groups"):
+        predict_video(m, u8[:12].to(dev), gp, op_, batch_size=2, overlap=True)              # one whole group + a tail
