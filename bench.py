@@ -851,6 +851,28 @@ def main():
                             "(two replicas, two host streams, Engine.run_streamed); priors as one broadcast map set (the caller's form); "
                             "overlapped_from_host: the frames start in pinned host memory (PCIe-inclusive) and are uploaded two groups ahead "
                             "on a copy stream"}
+                # the reference's own loop at ITS defaults (Demo_Test.py:110-125: batch_size 4 x time_dims 5 = groups of 20 frames)
+                model.time_dims = 5
+                model.invalidate_engines()
+                try:
+                    u5 = u8[:8].repeat(25, 1, 1, 1)             # 200 frames = 10 groups
+                    res5 = {}
+                    for ov in (False, True):
+                        predict_video(model, u5[:40], gp, op_, batch_size=4, overlap=ov)
+                        predict_video(model, u5[:40], gp, op_, batch_size=4, overlap=ov)
+                        torch.cuda.synchronize(device)
+                        t0 = time.perf_counter()
+                        sal5 = predict_video(model, u5, gp, op_, batch_size=4, overlap=ov)
+                        torch.cuda.synchronize(device)
+                        res5[ov] = (u5.shape[0] / (time.perf_counter() - t0), sal5)
+                    result["extra_video_stream"]["demo_default_groups_of_20"] = {
+                        "workload": "one video, 200 frames in groups of batch_size 4 x time_dims 5 (the reference's defaults), state carried",
+                        "sequential": round(res5[False][0], 2), "overlapped": round(res5[True][0], 2),
+                        "bit_identical": bool(torch.equal(res5[False][1], res5[True][1]))}
+                    del u5, res5
+                finally:
+                    model.time_dims = T
+                    model.invalidate_engines()
                 del u8, res_v, u8h
             except Exception as e:
                 result["extra_video_stream"] = {"error": repr(e)[:300]}
