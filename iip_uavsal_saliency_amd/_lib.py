@@ -25,7 +25,8 @@ ERR_STREAMK = 1
 DW_KERNEL = {1: "dw3x3_kernel<1, 4, 4>", 2: "dw3x3_kernel<1, 2, 2>", 3: "dw3x3_kernel<2, 2, 2>", 4: "dw3x3_dilated_kernel",
              16: "dw3x3_map_lds_kernel<16, 256>", 32: "dw3x3_map_lds_kernel<32, 256>", 64: "dw3x3_map_lds_kernel<64, 256>",
              528: "dw3x3_map_lds_kernel<16, 512>", 544: "dw3x3_map_lds_kernel<32, 512>", 576: "dw3x3_map_lds_kernel<64, 512>",
-             1040: "dw3x3_map_lds_kernel<16, 1024>", 1056: "dw3x3_map_lds_kernel<32, 1024>", 1088: "dw3x3_map_lds_kernel<64, 1024>"}
+             1040: "dw3x3_map_lds_kernel<16, 1024>", 1056: "dw3x3_map_lds_kernel<32, 1024>", 1088: "dw3x3_map_lds_kernel<64, 1024>",
+             2048: "dw3x3_rowclass_kernel<256>"}
 
 _f = C.c_void_p   # device pointers travel as integers
 

@@ -31,6 +31,8 @@ struct DwK {
     long long total;   // work items = n_img * tiles_y * tiles_x * C4
     int nblk;
     int dgc, dils[4];  // dgc > 0: channel c has dilation dils[c / dgc] (several dilated branches of one map in one launch)
+    int rc_first[5];   // dw3x3_rowclass_kernel: first virtual block of every dilation group (and the total)
+    int rc_q[4];       //   and the channel quads per slab of the group (16 / 32 / 64: the fewer rows a class has, the wider the slab)
 };
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -157,6 +159,12 @@ __global__ __launch_bounds__(256) void dw3x3_dilated_kernel(const DwK p) {
 // i.e. behind another L2 -- every line was fetched from and written to the memory side twice.  720x1280, 64 frames, 23x40 x
 // 5760 channels (aspp.dw of BASELINE configs[4]): 0.37 of 8 TB/s before (profiles/r4_bench_720p_c4_t16.json).
 __device__ __attribute__((aligned(16))) float g_dw_zero[4];
+#ifdef UAVSAL_DW_STAMPS       // diagnostic build only: s_memrealtime (100 MHz) at the phase boundaries of the first 16384 workgroups
+__device__ unsigned long long g_dw_stamps[4 * 16384];
+#define DW_STAMP(k) { if (threadIdx.x == 0 && blockIdx.x < 16384) g_dw_stamps[blockIdx.x * 4 + (k)] = __builtin_amdgcn_s_memrealtime(); }
+#else
+#define DW_STAMP(k)
+#endif
 
 template <int CB, int NT = 256>
 __global__ __launch_bounds__(NT) void dw3x3_map_lds_kernel(const DwK p) {
@@ -175,6 +183,7 @@ __global__ __launch_bounds__(NT) void dw3x3_map_lds_kernel(const DwK p) {
     const float* inb = p.in + (size_t)n * HW * p.ldi + c;
     f32x4* sm = reinterpret_cast<f32x4*>(smap);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    DW_STAMP(0)
     for (int i0 = 0; i0 < HW * Q; i0 += NT) {      // (the LDS image is padded to whole NT-item rounds: launch_map_lds)
         const int i = i0 + threadIdx.x;
         const int pix = i / Q;
@@ -187,7 +196,9 @@ __global__ __launch_bounds__(NT) void dw3x3_map_lds_kernel(const DwK p) {
     for (int k = 0; k < 9; ++k) wt[k] = ld4(p.w9c + (size_t)k * (p.C4 * 4) + cc);
     const f32x4 sc = ld4(p.scale + cc), bi = ld4(p.bias + cc);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    DW_STAMP(1)
     __syncthreads();
+    DW_STAMP(2)
     if (!cok) return;
     const int dil = p.dgc ? p.dils[c0 / p.dgc] : p.dil;          // (a slab never straddles two groups: dgc % CB == 0)
     float* outb = p.out + (size_t)n * HW * p.ldo + c;
@@ -213,6 +224,135 @@ __global__ __launch_bounds__(NT) void dw3x3_map_lds_kernel(const DwK p) {
         }
         *reinterpret_cast<f32x4*>(outb + (size_t)pix * p.ldo) = v;
     }
+#ifdef UAVSAL_DW_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    DW_STAMP(3)
+#endif
+}
+
+#ifdef UAVSAL_DW_STAMPS
+extern "C" int uavsal_dw_stamps(unsigned long long* dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_dw_stamps), sizeof(unsigned long long) * 4 * 16384);
+}
+#endif
+
+// Dilated maps, by ROW CLASS (round 5).  Output row oy of a dilation-d conv reads the input rows oy - d, oy, oy + d only: rows of
+// the same residue r = oy % d.  A workgroup therefore stages, instead of the whole map for a 16-channel slab (64 bytes per pixel:
+// every global access of dw3x3_map_lds_kernel is half a cache line at a 23 KB stride, and at 720x1280 x 64 frames the HBM sees
+// 2.7 GB of them at 4.15 TB/s), the <= ceil(H / d) rows of ONE class for a slab of CB = 64 channels: 256 contiguous bytes per
+// pixel, 41 KB of LDS for the four rows of a d = 6 class of the 23x40 map (three workgroups per CU), 20 KB for d = 12 / 18.
+// Blocks are numbered [dilation group][image][class][slab] with the slab fastest, and renumbered per XCD: the workgroups running
+// side by side on an XCD read neighbouring 256-byte pieces of the same pixels.  Each byte is still fetched once.
+// Item i of the LDS image = (class row j, column x, channel quad q), lane-linear (LDS-DMA); a thread keeps one channel quad.
+template <int NT>
+__global__ __launch_bounds__(NT) void dw3x3_rowclass_kernel(const DwK p) {
+    extern __shared__ __attribute__((aligned(16))) float smap[];
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    int vb = xcd_virtual_block(blockIdx.x, gridDim.x);
+    int g = 0;
+    while (g < 3 && vb >= p.rc_first[g + 1]) ++g;
+    vb -= p.rc_first[g];
+    const int Q = p.rc_q[g], CB = Q * 4;             // (NT % Q == 0: a thread keeps one channel quad)
+    const int C = p.C4 * 4;
+    const int gc0 = p.dgc ? g * p.dgc : 0;
+    const int gcw = p.dgc ? (C - gc0 < p.dgc ? C - gc0 : p.dgc) : C;          // channels of this group
+    const int d = p.dgc ? p.dils[g] : p.dil;
+    const int slabs = (gcw + CB - 1) / CB, classes = d < p.H ? d : p.H;
+    const int slab = vb % slabs; vb /= slabs;
+    const int r = vb % classes;
+    const int n = vb / classes;
+    const int k = (p.H - 1 - r) / d + 1;             // rows r, r + d, ... of this class
+    const int q = threadIdx.x % Q;
+    const int cl = slab * CB + q * 4;                // channel inside the group
+    const bool cok = cl < gcw;
+    const int c = gc0 + (cok ? cl : 0);
+    const int items = k * p.W * Q;
+    const float* inb = p.in + (size_t)n * p.H * p.W * p.ldi + c;
+    const f32x4* sm = reinterpret_cast<const f32x4*>(smap);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int i0 = 0; i0 < items; i0 += NT) {         // (the LDS image is padded to whole NT-item rounds: launch_rowclass)
+        const int i = i0 + threadIdx.x;
+        const int px = i / Q, j = px / p.W, x = px - j * p.W;
+        const float* src = (cok && i < items) ? inb + ((size_t)(r + j * d) * p.W + x) * p.ldi : g_dw_zero;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smap + (size_t)(i0 + wave * 64) * 4), 16, 0, 0);
+    }
+    f32x4 wt[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wt[t] = ld4(p.w9c + (size_t)t * C + c);
+    const f32x4 sc = ld4(p.scale + c), bi = ld4(p.bias + c);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (!cok) return;
+    float* outb = p.out + (size_t)n * p.H * p.W * p.ldo + c;
+    for (int i = threadIdx.x; i < items; i += NT) {
+        const int px = i / Q, j = px / p.W, x = px - j * p.W;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int jj = j + ky - 1;
+            if (jj < 0 || jj >= k) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = x + (kx - 1) * d;
+                if (ix < 0 || ix >= p.W) continue;
+                acc += sm[(jj * p.W + ix) * Q + q] * wt[ky * 3 + kx];
+            }
+        }
+        f32x4 v = acc * sc + bi;
+        if (p.act == UAVSAL_ACT_RELU6) {
+            v.x = fminf(fmaxf(v.x, 0.f), 6.f); v.y = fminf(fmaxf(v.y, 0.f), 6.f);
+            v.z = fminf(fmaxf(v.z, 0.f), 6.f); v.w = fminf(fmaxf(v.w, 0.f), 6.f);
+        }
+        *reinterpret_cast<f32x4*>(outb + ((size_t)(r + j * d) * p.W + x) * p.ldo) = v;
+    }
+}
+
+// quads per slab of a group: the widest of 64 / 32 / 16 whose largest class stays within `budget` items (0: none does);
+// the group's channels must be whole slabs of it
+static inline int rowclass_quads(const DwK& k, int g, long long budget) {
+    const int d = k.dgc ? k.dils[g] : k.dil;
+    const int C = k.C4 * 4, gcw = k.dgc ? (C - g * k.dgc < k.dgc ? C - g * k.dgc : k.dgc) : C;
+    const long long rows = (k.H - 1) / d + 1;
+    for (int q = 64; q >= 8; q >>= 1)
+        if (rows * k.W * q <= budget && gcw % (4 * q) == 0) return q;
+    return 0;
+}
+
+static const long long ROWCLASS_ITEMS = [] { const char* e = getenv("UAVSAL_DW_ROWCLASS_ITEMS"); return e ? atoll(e) : 2560LL; }();       // 40 KB of LDS per workgroup: three per CU
+
+static inline bool rowclass_fits(const DwK& k) {
+    const int groups = k.dgc ? (k.C4 * 4 + k.dgc - 1) / k.dgc : 1;
+    for (int g = 0; g < groups && g < 4; ++g)
+        if (!rowclass_quads(k, g, ROWCLASS_ITEMS)) return false;
+    return true;
+}
+
+template <int NT>
+int launch_rowclass(DwK k, hipStream_t s) {
+    const int C = k.C4 * 4;
+    const int groups = k.dgc ? (C + k.dgc - 1) / k.dgc : 1;
+    long long first = 0, most = 0;
+    for (int g = 0; g < 4; ++g) {
+        k.rc_first[g] = (int)first;
+        k.rc_q[g] = 16;
+        if (g < groups) {
+            const int d = k.dgc ? k.dils[g] : k.dil;
+            const int gcw = k.dgc ? (C - g * k.dgc < k.dgc ? C - g * k.dgc : k.dgc) : C;
+            const int q = rowclass_quads(k, g, ROWCLASS_ITEMS);
+            if (!q) return UAVSAL_ESHAPE;
+            k.rc_q[g] = q;
+            const long long items = (long long)((k.H - 1) / d + 1) * k.W * q;
+            if (items > most) most = items;
+            first += (long long)k.n_img * (gcw / (4 * q)) * (d < k.H ? d : k.H);
+        }
+        if (first > 0x7fffffffLL) return UAVSAL_ESHAPE;
+    }
+    k.rc_first[4] = (int)first;
+    const size_t smem = (size_t)((most + NT - 1) / NT * NT) * 16;
+    UAVSAL_LDS_OPTIN((&dw3x3_rowclass_kernel<NT>), smem);
+    hipLaunchKernelGGL((dw3x3_rowclass_kernel<NT>), dim3((unsigned)first), dim3(NT), smem, s, k);
+    return uavsal_launch_status();
 }
 
 // LDS image of a slab: [pixel][CB / 4] float4 items, padded to whole rounds of 256 items (one LDS-DMA request per wave and round)
@@ -261,6 +401,13 @@ static inline int map_lds_slab(const DwK& k) {
 static int dw_variant(const DwK& k, int stride, int dilation) {
     if (k.dgc) {              // several dilated branches in one launch: the whole-map kernel (each byte fetched once whatever the dilation)
         const int cb = map_lds_slab(k);
+        // a map too big for 32-channel slabs (23x40, the 1/32 level of 720x1280 inputs) would be read and written in half cache
+        // lines: by row class instead (measured at 64 frames x 5760 channels, in the plan: 577 vs 652 us, 0.588 vs 0.520 of 8 TB/s;
+        // on the 12x20 map of 360x640 inputs the whole-map kernel wins, 20 vs 26 us at 8 frames and 142 vs 181 at 64).
+        // UAVSAL_DW_ROWCLASS=0 / 1: never / wherever it fits
+        static const int rowclass = [] { const char* e = getenv("UAVSAL_DW_ROWCLASS"); return e ? atoi(e) : -1; }();
+        const bool big_map = map_lds_bytes((long long)k.H * k.W, 32) > 65536;
+        if (rowclass != 0 && (rowclass > 0 || big_map) && rowclass_fits(k)) return 2048;
         return (cb && k.dgc % cb == 0) ? cb : 4;
     }
     // Measured at 8 x 12x20 x 1920 (profiles/r2_dw_small_maps.md): the whole-map LDS kernel wins only while most
@@ -419,6 +566,8 @@ extern "C" int uavsal_dw3x3(const uavsal_dw_desc* d, uavsal_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     const int v = dw_variant(k, d->stride, d->dilation);
     switch (v) {
+        case 2048: { static const int nt = [] { const char* e = getenv("UAVSAL_DW_ROWCLASS_NT"); return e ? atoi(e) : 256; }();
+                     return nt == 256 ? launch_rowclass<256>(k, s) : launch_rowclass<512>(k, s); }
         case 64: return launch_map_lds<64>(k, s);
         case 32: return launch_map_lds<32>(k, s);
         case 16: return launch_map_lds<16>(k, s);
@@ -442,7 +591,10 @@ extern "C" int uavsal_dw_variant(const uavsal_dw_desc* d) {
     DwK k;
     k.H = d->H; k.W = d->W; k.Ho = (d->H - 1) / d->stride + 1; k.Wo = (d->W - 1) / d->stride + 1;
     k.C4 = d->C / 4; k.n_img = d->n_img; k.dgc = d->dil_group_c > 0 ? d->dil_group_c : 0;
+    k.dil = d->dilation;
+    for (int i = 0; i < 4; ++i) k.dils[i] = d->dil_groups[i] > 0 ? d->dil_groups[i] : 1;
     const int v = dw_variant(k, d->stride, d->dilation);
+    if (v >= 2048) return v;
     const int nt = v >= 16 ? map_lds_threads(k, v) : 256;
     return nt == 256 ? v : v + nt;
 }

@@ -227,7 +227,9 @@ int uavsal_dw3x3(const uavsal_dw_desc* d, uavsal_stream_t stream);
 /* kernel instance `uavsal_dw3x3` will use for this descriptor; no launch.  1: dw3x3_kernel<1,4,4> (4x4 output
  * patch per thread), 2: <1,2,2>, 3: <2,2,2> (stride 2), 4: dw3x3_dilated_kernel (one pixel per thread),
  * 16 / 32 / 64: dw3x3_map_lds_kernel<CB, 256> (whole map of a CB-channel slab staged in LDS by LDS-DMA; small maps, any
- * dilation), + 512 (528 / 544 / 576) for its 512-thread instance (slabs of >= 2048 float4 items) */
+ * dilation), + 512 (528 / 544 / 576) for its 512-thread instance (slabs of >= 2048 float4 items),
+ * 2048: dw3x3_rowclass_kernel<256> (merged dilated branches on a map too big for 32-channel whole-map slabs: a workgroup stages
+ * the rows of one residue class oy % dilation for a 64..256-channel slab) */
 int uavsal_dw_variant(const uavsal_dw_desc* d);
 
 /*

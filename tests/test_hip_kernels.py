@@ -7,6 +7,8 @@ slicing), on seeded inputs.  Tolerances are written next to each check:
   bf16   : single bf16 MFMA, ~2^-8 relative                    -> 3e-2 * scale
 """
 import numpy as np
+import ctypes
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -621,7 +623,14 @@ def test_depthwise(ops, case):
 
 
 @pytest.mark.parametrize("case", [(8, 12, 20, 3 * 1920, (6, 12, 18)), (2, 9, 13, 192, (2, 3, 5)), (1, 45, 80, 128, (1, 4)), (2, 130, 140, 96, (3, 7, 1)),
-                                  (48, 9, 13, 3 * 960, (6, 2, 3))])        # (the last one: 4320 workgroups of the whole-map kernel)
+                                  (48, 9, 13, 3 * 960, (6, 2, 3)),         # (4320 workgroups of the whole-map kernel)
+                                  # maps too big for 32-channel whole-map slabs: dw3x3_rowclass_kernel (rows of one residue class per
+                                  # workgroup).  The 1/32 level of 720x1280 inputs; narrow groups (32-channel slabs); a dilation beyond
+                                  # the map (every row its own class) next to a small one; one group only
+                                  (4, 23, 40, 3 * 1920, (6, 12, 18)), (2, 23, 40, 3 * 96, (6, 12, 18)), (3, 25, 33, 2 * 64, (30, 5)),
+                                  (2, 20, 30, 64, (40,)),
+                                  # a group whose classes do not fit (dilation 2: 12 rows): the whole launch stays on the other kernels
+                                  (1, 23, 40, 4 * 32, (2, 6, 12, 18))])
 def test_depthwise_channel_groups_with_their_own_dilation(ops, case):
     """uavsal_dw_desc.dil_group_c: the dilated branches of one map in one launch (the three ASPP depthwise convs on the slices of
     their merged expand, model.py:125-127, 142-147) == one torch depthwise conv per group.  Whole-map LDS kernel where the map
@@ -635,6 +644,14 @@ def test_depthwise_channel_groups_with_their_own_dilation(ops, case):
     ref = torch.clamp(ref * sd.view(1, -1, 1, 1) + bd.view(1, -1, 1, 1), 0, 6)
     got = ops.dw3x3(nhwc(x), wd, sd, bd, dil_groups=list(dils))
     assert (nchw(got) - ref).abs().max().item() <= 2e-5, case
+    from iip_uavsal_saliency_amd import _lib as L
+    d = L.DwDesc()
+    d.n_img, d.H, d.W, d.C, d.stride, d.dilation, d.dil_group_c = n, h, w, c, 1, 1, g
+    for i, dd in enumerate(dils):
+        d.dil_groups[i] = dd
+    variant = L.load().uavsal_dw_variant(ctypes.byref(d))
+    assert (variant == 2048) == (case in ((4, 23, 40, 3 * 1920, (6, 12, 18)), (2, 23, 40, 3 * 96, (6, 12, 18)), (3, 25, 33, 2 * 64, (30, 5)),
+                                          (2, 20, 30, 64, (40,)))), (case, variant)
     with pytest.raises(RuntimeError):
         ops.dw3x3(nhwc(x), wd, sd, bd, stride=2, dil_groups=list(dils))
 
