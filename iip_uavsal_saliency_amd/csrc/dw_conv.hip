@@ -237,13 +237,15 @@ extern "C" int uavsal_dw_stamps(unsigned long long* dst) {
 #endif
 
 // Dilated maps, by ROW CLASS (round 5).  Output row oy of a dilation-d conv reads the input rows oy - d, oy, oy + d only: rows of
-// the same residue r = oy % d.  A workgroup therefore stages, instead of the whole map for a 16-channel slab (64 bytes per pixel:
-// every global access of dw3x3_map_lds_kernel is half a cache line at a 23 KB stride, and at 720x1280 x 64 frames the HBM sees
-// 2.7 GB of them at 4.15 TB/s), the <= ceil(H / d) rows of ONE class for a slab of CB = 64 channels: 256 contiguous bytes per
-// pixel, 41 KB of LDS for the four rows of a d = 6 class of the 23x40 map (three workgroups per CU), 20 KB for d = 12 / 18.
+// the same residue r = oy % d.  Instead of the whole map for a 16-channel slab (64 bytes per pixel: every global access of
+// dw3x3_map_lds_kernel is half a cache line at a 23 KB stride, and at 720x1280 x 64 frames the HBM sees 2.7 GB of them at
+// 4.15 TB/s) a workgroup stages the <= ceil(H / d) rows of ONE class for a slab of 4 * rc_q[group] channels -- the fewer rows a
+// class has, the wider the slab (launch_rowclass): 64 channels for the four rows of a d = 6 class of the 23x40 map, 128 for the
+// one or two rows at d = 12 / 18; 256-512 contiguous bytes per pixel, <= 40 KB of LDS, three workgroups per CU.
 // Blocks are numbered [dilation group][image][class][slab] with the slab fastest, and renumbered per XCD: the workgroups running
-// side by side on an XCD read neighbouring 256-byte pieces of the same pixels.  Each byte is still fetched once.
+// side by side on an XCD read neighbouring pieces of the same pixels.  Each byte is still fetched once (PMC: 2.73 GB for 2.71).
 // Item i of the LDS image = (class row j, column x, channel quad q), lane-linear (LDS-DMA); a thread keeps one channel quad.
+// 652 -> 577 us in the 720x1280 plan (0.520 -> 0.588 of 8 TB/s); profiles/r5_experiments.md has the versions.
 template <int NT>
 __global__ __launch_bounds__(NT) void dw3x3_rowclass_kernel(const DwK p) {
     extern __shared__ __attribute__((aligned(16))) float smap[];
