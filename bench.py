@@ -489,6 +489,9 @@ def main():
     ap.add_argument("--persistent-state", type=int, default=0, help="1: BASELINE configs[4]'s mode -- the recurrent state stays in the "
                     "engine's HBM buffer between steps (model.persistent_state) and every step continues from the previous one's state; "
                     "0: every step gets a caller-owned state tensor (staged NCHW -> NHWC, returned as a fresh NCHW tensor)")
+    ap.add_argument("--inflight", type=int, default=1, help="N > 1: the K steps are issued through stream.RequestPipeline, N independent requests "
+                    "in flight on N host streams / lane-less model handles (per-request results bitwise unchanged; one GPU, caller-owned state).  "
+                    "NOT the default: `value` of `python bench.py` is one request at a time; the same figure is in its `extra_two_requests_in_flight`")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true", help="with --gpus N: the N ranks all use cuda:0 and rendezvous over gloo "
                     "(maps gathered through the host).  NOT a measurement of anything -- it runs the launcher, the rank environment, the "
                     "clip partition, the gather and the barrier-bracketed timing with the HIP engine on a one-GPU box; the line says so")
@@ -549,7 +552,17 @@ def main():
     gathered = torch.empty((C * world, T, 1, h, w), device=device) if distributed else None
     last = {}
 
+    pipe = None
+    if args.inflight > 1:
+        if distributed or args.persistent_state or args.graph:
+            raise SystemExit("--inflight N > 1 is a one-GPU, launch-loop, caller-owned-state measurement")
+        from iip_uavsal_saliency_amd.stream import RequestPipeline
+        pipe = RequestPipeline(model, streams=args.inflight)
+
     def step():
+        if pipe is not None:      # independent requests (zero state each), N in flight; timed_steps synchronises the whole device
+            last["out"], last["state"], _ = pipe.forward_clips(x, cb, state)
+            return
         # persistent mode: continue from the state the previous step left in HBM (recognised by address: no copy)
         out, st = model.forward_clips(x, cb, last.get("state", None) if args.persistent_state else state)
         if distributed:
@@ -560,7 +573,8 @@ def main():
     # first launches.  Demo_Test.py:75-86 pays it once per video shape -- and once more (plan only) for a short last group
     torch.cuda.synchronize(device)
     t_first = time.perf_counter()
-    step()
+    for _ in range(max(1, args.inflight)):          # (every in-flight handle records its plan)
+        step()
     torch.cuda.synchronize(device)
     first_call_ms = (time.perf_counter() - t_first) * 1e3
     log("model + inputs ready (first call %.0f ms); timing %d steps" % (first_call_ms, args.steps))
@@ -579,14 +593,20 @@ def main():
         "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "windows_ms_per_step": [round(w / args.steps * 1e3, 4) for w in wins],
         "vs_baseline": None, "dtype": DTYPE_NAME[args.prec], "data": "synthetic",
-        "config": {"workload": "%dx%d batch=%d clip(s)/GPU seq=%d, UAVSal.forward_clips, prec=%s, %s" % (
-            H, W, C, T, args.prec, "hipGraph replay" if args.graph else "launch loop"),
+        "config": {"workload": "%dx%d batch=%d clip(s)/GPU seq=%d, UAVSal.forward_clips, prec=%s, %s%s" % (
+            H, W, C, T, args.prec, "hipGraph replay" if args.graph else "launch loop",
+            ", %d independent requests in flight (stream.RequestPipeline)" % args.inflight if pipe is not None else ""),
+            "requests_in_flight": max(1, args.inflight),
             "clips_per_gpu": C, "seq_len": T, "height": H, "width": W, "precision": args.prec,
             "persistent_state": bool(args.persistent_state),
             "parallelism": "clip-sharded x%d, one all-gather of maps per step" % world if distributed else "single GPU"},
     }
 
     result["ranks_seen"] = dist.get_world_size() if distributed else 1
+    if pipe is not None:
+        pipe.synchronize()
+        so, ss = model.forward_clips(x, cb, state)
+        result["bit_identical_to_one_at_a_time"] = bool(torch.equal(last["out"], so) and torch.equal(last["state"], ss))
     if rehearsal:
         result["n_gpus"] = 1
         result["rehearsal"] = ("%d ranks SHARING one GPU over gloo (maps gathered through the host): exercises launcher, rank env, clip "

@@ -45,6 +45,7 @@ want f32_c4_720x1280_t16 && run_set f32 4 "bench.py --height 720 --width 1280 --
 fi
 cd $R
 want f32_c1 && python3 bench.py > $O/r5_bench_default.json 2> $O/r5_bench_default.err
+want f32_c1 && python3 bench.py --inflight 2 --no-extra > $O/r5_bench_inflight2.json 2> $O/r5_bench_inflight2.err
 want f32_c8 && python3 bench.py --clips 8 --no-extra --no-cpu-baseline > $O/r5_bench_f32_c8.json 2> $O/r5_bench_f32_c8.err
 want f16x3_c8 && python3 bench.py --prec f16x3 --clips 8 --no-extra --no-cpu-baseline > $O/r5_bench_f16x3_c8.json 2> $O/r5_bench_f16x3_c8.err
 want f16x3_c8 && python3 bench.py --prec f16x3 --no-extra --no-cpu-baseline > $O/r5_bench_f16x3_c1.json 2> $O/r5_bench_f16x3_c1.err
